@@ -1,0 +1,253 @@
+"""Pins the CPU oracle before anything is compared against it.
+
+The reference ships no tests, so the pins are: scipy.stats / torch.distributions
+cross-checks, published known answers, fp64 central differences, and the exact
+harmonic-oscillator leapfrog orbit of the reference's README.md:571-591.
+"""
+import math
+
+import numpy as np
+import pytest
+import scipy.stats as st
+import torch
+
+from oracle import closed_form as cf
+from oracle import leapfrog as lf
+from oracle import restated_torch as rt
+
+
+def _fd(f, x, eps=1e-6):
+    g = np.zeros_like(x)
+    for idx in np.ndindex(*x.shape):
+        xp = x.copy(); xm = x.copy()
+        xp[idx] += eps; xm[idx] -= eps
+        g[idx] = (f(xp)[idx[0]] - f(xm)[idx[0]]) / (2 * eps)
+    return g
+
+
+def test_known_answers():
+    y = np.array([6.1, 7.9, 3.2, 10.4])
+    lp, _ = cf.normal_iid(y, np.array([[6.8, 2.4]]))
+    assert lp[0] == pytest.approx(-9.575198526678735, abs=1e-12)
+    lp, _ = cf.halfnormal_prior(2.4, 10.0)
+    assert float(lp) == pytest.approx(-2.557176445638773, abs=1e-12)
+
+
+def test_priors_vs_scipy_and_torch():
+    x = np.array([-1.3, 0.2, 4.0])
+    lp, g = cf.normal_prior(x, 0.5, 10.0)
+    np.testing.assert_allclose(lp, st.norm(0.5, 10.0).logpdf(x), rtol=1e-13)
+    xs = np.array([0.3, 2.4, 11.0])
+    lp, _ = cf.halfnormal_prior(xs, 10.0)
+    np.testing.assert_allclose(lp, st.halfnorm(scale=10.0).logpdf(xs), rtol=1e-13)
+    np.testing.assert_allclose(
+        lp, torch.distributions.HalfNormal(torch.tensor(10.0, dtype=torch.float64)).log_prob(torch.tensor(xs)).numpy(),
+        rtol=1e-13)
+    w = np.array([0.2, 0.5, 0.3]); a = np.array([1.5, 2.0, 0.7])
+    lp, _ = cf.dirichlet_prior(w, a)
+    assert float(lp) == pytest.approx(st.dirichlet(a).logpdf(w), rel=1e-12)
+    lp, _ = cf.dirichlet_prior(w, np.ones(3))
+    assert float(lp) == pytest.approx(math.lgamma(3), rel=1e-12)
+
+
+def test_normal_iid_vs_scipy_and_fd():
+    rng = np.random.default_rng(0)
+    y = rng.normal(7, 3, 50)
+    th = np.array([[6.5, 2.8], [0.1, 9.0], [7.2, 0.9]])
+    lp, g = cf.normal_iid(y, th)
+    ref = np.array([st.norm(t[0], t[1]).logpdf(y).sum() for t in th])
+    np.testing.assert_allclose(lp, ref, rtol=1e-12)
+    np.testing.assert_allclose(g, _fd(lambda t: cf.normal_iid(y, t)[0], th), rtol=1e-6, atol=1e-6)
+
+
+def test_linreg_vs_scipy_and_fd():
+    rng = np.random.default_rng(1)
+    X = rng.normal(size=(40, 5)); y = rng.normal(size=40)
+    th = np.concatenate([rng.normal(size=(3, 6)), rng.uniform(0.5, 2, (3, 1))], -1)
+    lp, g = cf.linreg(X, y, th)
+    ref = np.array([st.norm(t[0] + X @ t[1:6], t[6]).logpdf(y).sum() for t in th])
+    np.testing.assert_allclose(lp, ref, rtol=1e-12)
+    np.testing.assert_allclose(g, _fd(lambda t: cf.linreg(X, y, t)[0], th), rtol=1e-6, atol=1e-6)
+
+
+def test_gmm1d_vs_torch_and_fd():
+    rng = np.random.default_rng(2)
+    k = 3
+    y = np.concatenate([rng.normal(-5, 1, 30), rng.normal(4, 2, 30)])
+    th = np.concatenate([rng.dirichlet(np.ones(k), 2), rng.normal(0, 4, (2, k)), rng.uniform(0.5, 3, (2, k))], -1)
+    lp, g = cf.gmm1d(y, th, k)
+    for c in range(2):
+        t = torch.tensor(th[c])
+        mix = torch.distributions.MixtureSameFamily(
+            torch.distributions.Categorical(probs=t[:k]),
+            torch.distributions.Normal(t[k:2 * k], t[2 * k:]))
+        assert lp[c] == pytest.approx(mix.log_prob(torch.tensor(y)).sum().item(), rel=1e-12)
+    np.testing.assert_allclose(g, _fd(lambda t: cf.gmm1d(y, t, k)[0], th), rtol=2e-6, atol=2e-6)
+    # un-normalised weights: Categorical(probs=w) renormalises, so scaling w leaves logp unchanged
+    th2 = th.copy(); th2[:, :k] *= 3.0
+    np.testing.assert_allclose(cf.gmm1d(y, th2, k)[0], lp, rtol=1e-12)
+
+
+def test_gmm_fullcov_vs_torch_and_fd():
+    rng = np.random.default_rng(3)
+    c, k, d, n = 2, 3, 4, 25
+    Y = rng.normal(size=(n, d)) * 2
+    w = rng.dirichlet(np.ones(k), c); mu = rng.normal(size=(c, k, d))
+    L = np.tril(rng.normal(size=(c, k, d, d)) * 0.3)
+    for i in range(d):
+        L[..., i, i] = rng.uniform(0.7, 1.5, (c, k))
+    lp, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+    for ci in range(c):
+        mix = torch.distributions.MixtureSameFamily(
+            torch.distributions.Categorical(probs=torch.tensor(w[ci])),
+            torch.distributions.MultivariateNormal(torch.tensor(mu[ci]), scale_tril=torch.tensor(L[ci])))
+        assert lp[ci] == pytest.approx(mix.log_prob(torch.tensor(Y)).sum().item(), rel=1e-11)
+    wt = torch.tensor(w, requires_grad=True); mt = torch.tensor(mu, requires_grad=True)
+    Lt = torch.tensor(L, requires_grad=True)
+    tot = 0
+    for ci in range(c):
+        mix = torch.distributions.MixtureSameFamily(
+            torch.distributions.Categorical(probs=wt[ci]),
+            torch.distributions.MultivariateNormal(mt[ci], scale_tril=Lt[ci]))
+        tot = tot + mix.log_prob(torch.tensor(Y)).sum()
+    tot.backward()
+    np.testing.assert_allclose(gw, wt.grad.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gmu, mt.grad.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gL, np.tril(Lt.grad.numpy()), rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize('bij,n', [(cf.Softplus(), 3), (cf.Exp(), 2), (cf.SoftmaxCentered(), 4),
+                                   (cf.FillScaleTriL(3, 1e-3), 6), (cf.Identity(), 2)])
+def test_bijectors_jacobians(bij, n):
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(2, n))
+    y = bij.forward(x)
+    if not isinstance(bij, cf.FillScaleTriL):
+        np.testing.assert_allclose(bij.inverse(y), x, rtol=1e-9, atol=1e-9)
+    # numerical Jacobian
+    eps = 1e-6
+    for b in range(2):
+        J = np.zeros((y.shape[-1], n))
+        for j in range(n):
+            xp = x[b].copy(); xm = x[b].copy(); xp[j] += eps; xm[j] -= eps
+            J[:, j] = (bij.forward(xp[None])[0] - bij.forward(xm[None])[0]) / (2 * eps)
+        if isinstance(bij, cf.FillScaleTriL):
+            rows = [i * bij.d + j for i in range(bij.d) for j in range(i + 1)]
+            Jsq = J[rows]
+            ref = np.linalg.slogdet(Jsq)[1]
+        else:
+            ref = 0.5 * np.linalg.slogdet(J.T @ J)[1]
+        assert bij.fldj(x)[b] == pytest.approx(ref, abs=1e-6)
+        g = rng.normal(size=y.shape[-1])
+        np.testing.assert_allclose(bij.vjp(x[b:b + 1], g[None])[0], J.T @ g, rtol=1e-6, atol=1e-7)
+    gf = _fd(lambda t: bij.fldj(t), x)
+    np.testing.assert_allclose(bij.grad_fldj(x), gf, rtol=1e-6, atol=1e-7)
+
+
+def test_fill_triangular_example():
+    bij = cf.FillScaleTriL(3, 0.0)
+    idx = bij.index
+    x = np.arange(1, 7, dtype=float)
+    m = np.where(idx >= 0, x[np.maximum(idx, 0)], 0.0)
+    np.testing.assert_array_equal(m, [[4, 0, 0], [6, 5, 0], [3, 2, 1]])
+
+
+@pytest.mark.parametrize('maker', ['normal', 'linreg', 'gmm'])
+def test_unconstrained_posterior_gradient(maker):
+    rng = np.random.default_rng(5)
+    if maker == 'normal':
+        m = cf.normal_model(rng.normal(7, 3, 20))
+    elif maker == 'linreg':
+        X = rng.normal(size=(30, 3)); m = cf.linreg_model(X, X @ [1.0, -2.0, 0.5] + 0.3 + rng.normal(size=30))
+    else:
+        m = cf.gmm1d_model(np.concatenate([rng.normal(-4, 1, 20), rng.normal(3, 1, 20)]), 3)
+    z = rng.uniform(-1, 1, (3, m.pu))
+    lp, g = m.log_post_unconstrained(z)
+    np.testing.assert_allclose(g, _fd(lambda t: m.log_post_unconstrained(t)[0], z), rtol=5e-6, atol=5e-6)
+    th = m.constrain(z)
+    np.testing.assert_allclose(m.unconstrain(th), z, rtol=1e-8, atol=1e-8)
+
+
+def test_leapfrog_harmonic_oscillator_orbit():
+    """README.md:571-591: U = q^2/2, T = p^2/2, eps = 0.5, n = 1, start (1, 0)."""
+    gU = lambda q: q
+    gT = lambda p: p
+    x = np.array([1.0, 0.0])
+    path = [x]
+    for _ in range(20):
+        path.append(lf.solve(gU, gT, path[-1], 0.5, 1))
+    path = np.stack(path)
+    np.testing.assert_allclose(path[1], [0.875, -0.46875], rtol=0, atol=0)
+    np.testing.assert_allclose(path[2], [0.53125, -0.8203125], rtol=0, atol=0)
+    np.testing.assert_allclose(path[20], [-0.7760410416, 0.6106556172], atol=1e-9)
+    inv = path[:, 0] ** 2 + path[:, 1] ** 2 / (1 - 0.5 ** 2 / 4)
+    np.testing.assert_allclose(inv, 1.0, atol=1e-12)
+    # inverse = same map with negated step (flow_bijectors.py:72-75)
+    np.testing.assert_allclose(lf.solve(gU, gT, path[5], -0.5, 1), path[4], atol=1e-14)
+    with pytest.raises(ValueError):
+        lf.solve(gU, gT, np.zeros(3), 0.1, 1)
+
+
+def test_hmc_step_reversible_and_detailed():
+    rng = np.random.default_rng(6)
+    m = cf.normal_model(rng.normal(7, 3, 20))
+    z = rng.uniform(-1, 1, (4, 2)) + np.array([6.0, 1.0])
+    p = rng.normal(size=(4, 2))
+    q1, p1, lp1, _ = lf.hmc_trajectory(m.log_post_unconstrained, z, p, 0.05, 7)
+    q0, p0, _, _ = lf.hmc_trajectory(m.log_post_unconstrained, q1, -p1, 0.05, 7)
+    np.testing.assert_allclose(q0, z, atol=1e-10)
+    np.testing.assert_allclose(-p0, p, atol=1e-10)
+    qn, acc, lr, lpn = lf.hmc_step(m.log_post_unconstrained, z, p, np.log(rng.uniform(size=4)), 0.002, 7)
+    assert np.all(np.abs(lr) < 0.05)         # small step => small energy error
+    assert qn.shape == z.shape and acc.dtype == bool
+
+
+def test_restated_torch_matches_closed_form():
+    rng = np.random.default_rng(7)
+    y = rng.normal(7, 3, 200).astype(np.float32)
+    th = np.array([[6.5, 2.8], [7.5, 3.3]], dtype=np.float32)
+    lp, g = cf.normal_iid(y, th)
+    v, gr = rt.normal_iid(torch.tensor(y), torch.tensor(th))
+    np.testing.assert_allclose(v.numpy(), lp, rtol=1e-5)
+    np.testing.assert_allclose(gr.numpy(), g, rtol=1e-4, atol=1e-4)
+    X = rng.normal(size=(300, 8)).astype(np.float32)
+    yy = (X @ rng.normal(size=8) + rng.normal(size=300)).astype(np.float32)
+    th = np.concatenate([rng.normal(size=(3, 9)), rng.uniform(0.8, 2, (3, 1))], -1).astype(np.float32)
+    lp, g = cf.linreg(X, yy, th)
+    v, gr = rt.linreg(torch.tensor(X), torch.tensor(yy), torch.tensor(th), chunk=128)
+    np.testing.assert_allclose(v.numpy(), lp, rtol=1e-5)
+    np.testing.assert_allclose(gr.numpy(), g, rtol=1e-4, atol=1e-3)
+    k = 4
+    ym = np.concatenate([rng.normal(-5, 1, 100), rng.normal(4, 2, 100)]).astype(np.float32)
+    th = np.concatenate([rng.dirichlet(np.ones(k), 2), rng.normal(0, 4, (2, k)), rng.uniform(0.5, 3, (2, k))], -1).astype(np.float32)
+    lp, g = cf.gmm1d(ym, th, k)
+    v, gr = rt.gmm1d(torch.tensor(ym), torch.tensor(th), k, chunk=64)
+    np.testing.assert_allclose(v.numpy(), lp, rtol=1e-5)
+    np.testing.assert_allclose(gr.numpy(), g, rtol=1e-4, atol=1e-3)
+
+
+def test_sufficient_statistic_posterior_table():
+    """univariate_gaussian_experiment/tables: NUTS posterior sd of loc ~ s/sqrt(N)
+    and of scale ~ s/sqrt(2N) for N = 100 (dataset_infos.txt:6-15 vs
+    mcmc_summary_statistics.txt:6-25, skipping the stuck-chain datasets 5 and 7).
+    Checked here against a Laplace approximation of the oracle's posterior."""
+    table = {1: (3.37, 1.65, 3.37, 0.16, 1.68, 0.12), 2: (-2.03, 2.45, -2.03, 0.25, 2.49, 0.18),
+             4: (4.59, 3.69, 4.59, 0.38, 3.76, 0.27), 9: (13.94, 1.82, 13.94, 0.18, 1.85, 0.13)}
+    for _, (m, s, pm, psd, sm, ssd) in table.items():
+        rng = np.random.default_rng(8)
+        y = rng.normal(size=100); y = (y - y.mean()) / y.std(ddof=1) * s + m
+        model = cf.normal_model(y)
+        # numeric Hessian of the constrained log posterior at its mode
+        th = np.array([[m, s]])
+        for _ in range(50):
+            _, g = model.log_post_constrained(th)
+            H = np.zeros((2, 2))
+            for j in range(2):
+                e = np.zeros((1, 2)); e[0, j] = 1e-5
+                H[:, j] = (model.log_post_constrained(th + e)[1] - model.log_post_constrained(th - e)[1])[0] / 2e-5
+            th = th - np.linalg.solve(H, g[0])[None]
+        cov = np.linalg.inv(-H)
+        assert th[0, 0] == pytest.approx(pm, abs=0.02)
+        assert math.sqrt(cov[0, 0]) == pytest.approx(psd, abs=0.015)
+        assert th[0, 1] == pytest.approx(sm, abs=0.06)       # mode < mean for the skewed scale posterior
+        assert math.sqrt(cov[1, 1]) == pytest.approx(ssd, abs=0.015)
