@@ -1,0 +1,133 @@
+"""ctypes binding of libbvi_hip.so (the C ABI declared in include/bvi.h).
+
+There is no CPU fallback: if the library is missing or an entry point fails the
+call raises.  Tensors are torch CUDA float32; kernels are enqueued on torch's
+current stream and nothing here synchronises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV = 0, 1, 2, 3
+PREC_AUTO, PREC_F32, PREC_BF16X3 = 0, 1, 2
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'libbvi_hip.so')
+_lib = None
+
+
+class BviError(RuntimeError):
+    """A libbvi_hip entry point returned a non-zero status."""
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """Load libbvi_hip.so once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise BviError(
+                'libbvi_hip.so not found at %s -- build it with `make -C bayesian-inference_amd/csrc` '
+                '(or __graft_entry__.build()); there is no CPU fallback' % _LIB_PATH)
+        l = ctypes.CDLL(_LIB_PATH)
+        vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+        l.bvi_version.restype = i32
+        l.bvi_status_string.restype = ctypes.c_char_p
+        l.bvi_status_string.argtypes = [i32]
+        l.bvi_workspace_bytes.argtypes = [i32, i64, i32, i32, i32, ctypes.POINTER(sz)]
+        l.bvi_normal_iid_logp_grad.argtypes = [vp, i64, vp, i32, vp, vp, vp, sz, vp]
+        l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
+        l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, sz, vp]
+        for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
+                     'bvi_gmm1d_logp_grad'):
+            getattr(l, name).restype = i32
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise BviError('%s failed with status %d: %s' % (what, status, lib().bvi_status_string(status).decode()))
+
+
+def workspace_bytes(family: int, n_rows: int, n_chains: int, d: int = 0, k: int = 0) -> int:
+    out = ctypes.c_size_t(0)
+    check(lib().bvi_workspace_bytes(family, n_rows, n_chains, d, k, ctypes.byref(out)), 'bvi_workspace_bytes')
+    return int(out.value)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_f32_cuda(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise BviError('libbvi_hip needs contiguous float32 CUDA tensors, got %s %s contiguous=%s'
+                           % (t.device, t.dtype, t.is_contiguous()))
+
+
+class Workspace:
+    """A grow-only device scratch buffer owned by the caller of the C ABI."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes: int):
+        nbytes = max(int(nbytes), 256)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def _outputs(theta, want_grad):
+    c = theta.shape[0]
+    logp = torch.empty(c, dtype=torch.float32, device=theta.device)
+    grad = torch.empty_like(theta) if want_grad else None
+    return logp, grad
+
+
+def normal_iid_logp_grad(y, theta, ws: Workspace, want_grad=True):
+    _check_f32_cuda(y, theta)
+    n, c = y.shape[0], theta.shape[0]
+    assert theta.shape == (c, 2)
+    logp, grad = _outputs(theta, want_grad)
+    buf = ws.get(workspace_bytes(FAMILY_NORMAL_IID, n, c))
+    check(lib().bvi_normal_iid_logp_grad(_ptr(y), n, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
+                                         buf.numel(), _stream()), 'bvi_normal_iid_logp_grad')
+    return logp, grad
+
+
+def linreg_logp_grad(X, y, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO):
+    _check_f32_cuda(X, y, theta)
+    n, d = X.shape
+    c = theta.shape[0]
+    assert y.shape == (n,) and theta.shape == (c, d + 2)
+    logp, grad = _outputs(theta, want_grad)
+    buf = ws.get(workspace_bytes(FAMILY_LINREG, n, c, d=d))
+    check(lib().bvi_linreg_logp_grad(_ptr(X), _ptr(y), n, d, _ptr(theta), c, precision, _ptr(logp), _ptr(grad),
+                                     _ptr(buf), buf.numel(), _stream()), 'bvi_linreg_logp_grad')
+    return logp, grad
+
+
+def gmm1d_logp_grad(y, theta, k, ws: Workspace, want_grad=True):
+    _check_f32_cuda(y, theta)
+    n, c = y.shape[0], theta.shape[0]
+    assert theta.shape == (c, 3 * k)
+    logp, grad = _outputs(theta, want_grad)
+    buf = ws.get(workspace_bytes(FAMILY_GMM1D, n, c, k=k))
+    check(lib().bvi_gmm1d_logp_grad(_ptr(y), n, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
+                                    buf.numel(), _stream()), 'bvi_gmm1d_logp_grad')
+    return logp, grad

@@ -1,0 +1,60 @@
+// extern "C" surface of libbvi_hip.so (declared in include/bvi.h): argument
+// checks, workspace sizing and dispatch to the per-family launchers.
+#include "bvi_common.h"
+
+extern "C" {
+
+int bvi_version(void) { return BVI_VERSION; }
+
+const char* bvi_status_string(int status) {
+  switch (status) {
+    case BVI_OK: return "ok";
+    case BVI_ERR_ARG: return "invalid argument (null pointer, negative size, misaligned X or bad enum)";
+    case BVI_ERR_UNSUPPORTED: return "shape or precision not supported by the gfx950 kernels";
+    case BVI_ERR_WORKSPACE: return "workspace missing or smaller than bvi_workspace_bytes()";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
+  }
+}
+
+int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, size_t* out_bytes) {
+  if (!out_bytes || n_rows < 0 || n_chains < 1) return BVI_ERR_ARG;
+  switch (family) {
+    case BVI_FAMILY_NORMAL_IID: *out_bytes = bvi_ws_normal_iid(n_rows, n_chains); break;
+    case BVI_FAMILY_LINREG:
+      if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+      *out_bytes = bvi_ws_linreg(n_rows, n_chains, d);
+      break;
+    case BVI_FAMILY_GMM1D:
+      if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
+      *out_bytes = bvi_ws_gmm1d(n_rows, n_chains, k);
+      break;
+    default: return BVI_ERR_UNSUPPORTED;
+  }
+  return BVI_OK;
+}
+
+int bvi_normal_iid_logp_grad(const float* y, int64_t n, const float* theta, int n_chains, float* logp,
+                             float* grad, void* ws, size_t ws_bytes, void* stream) {
+  if ((!y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (!ws || ws_bytes < bvi_ws_normal_iid(n, n_chains)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_normal_iid(y, n, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+}
+
+int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta, int n_chains,
+                         int precision, float* logp, float* grad, void* ws, size_t ws_bytes, void* stream) {
+  if (((!X || !y) && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X3) return BVI_ERR_ARG;
+  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < bvi_ws_linreg(n, n_chains, d)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_linreg(X, y, n, d, theta, n_chains, precision, logp, grad, (float*)ws, (hipStream_t)stream);
+}
+
+int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains, float* logp,
+                        float* grad, void* ws, size_t ws_bytes, void* stream) {
+  if ((!y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < bvi_ws_gmm1d(n, n_chains, k)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_gmm1d(y, n, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Shared device helpers and launch policy for libbvi_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bvi.h"
+
+#define BVI_LN2PI 1.8378770664093453f
+#define BVI_LN2PI_D 1.8378770664093453
+#define BVI_LOG2E 1.4426950408889634f
+#define BVI_LN2 0.6931471805599453f
+
+// Row-block count of the streaming kernels: enough workgroups to fill the
+// 256 CUs several times over, capped so the per-block partial sums stay small.
+#define BVI_MAX_ROW_BLOCKS 1024
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+static inline int bvi_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Smallest supported lanes-per-wave chain packing >= c (1, 4, 16 or 64).
+static inline int bvi_chain_pack(int c) { return c <= 1 ? 1 : c <= 4 ? 4 : c <= 16 ? 16 : 64; }
+
+#define BVI_HIP_CHECK_LAUNCH()                   \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+// Per-family launchers (defined in the .hip files), all: partial sums into ws,
+// then a finalize kernel that reduces them in fixed order.
+int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, float* logp, float* grad,
+                          float* ws, hipStream_t s);
+size_t bvi_ws_normal_iid(int64_t n, int c);
+
+int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c, float* logp, float* grad,
+                     float* ws, hipStream_t s);
+size_t bvi_ws_gmm1d(int64_t n, int c, int k);
+
+int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
+                      float* logp, float* grad, float* ws, hipStream_t s);
+size_t bvi_ws_linreg(int64_t n, int c, int d);
+
+#ifdef __HIPCC__
+// Sum over the lanes that share (lane % CP): butterfly over the upper lane bits.
+template <int CP>
+__device__ __forceinline__ float bvi_reduce_over_rowsubs(float v) {
+#pragma unroll
+  for (int off = 32; off >= CP; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+#endif

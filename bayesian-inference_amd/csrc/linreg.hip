@@ -1,0 +1,357 @@
+// Gaussian linear-regression likelihood and gradient for every chain: exact-f32
+// kernels (VALU for d <= 8, f32-input MFMA for d <= 64), the finalize step, and
+// the dispatcher that also routes to the bf16-split MFMA kernel
+// (linreg_bf16x3.hip).
+//
+// Replaces the feature-conditioned 'y' node tfd.Normal(beta_0 + X w, scale) of
+// bayes_vi/model/model.py:194-195,201-203 (README.md:754-756 with the features
+// as one [N,D] tensor, bayes_vi/utils/datasets.py:48-50) and its autodiff
+// gradient.  Maths, per chain c with r_i = y_i - beta_0 - x_i . w:
+//   S2 = sum r_i^2, S1 = sum r_i, G = sum r_i x_i            (raw sums, [d+2] per chain)
+//   logp = -S2/(2 s^2) - n log s - n/2 log 2pi
+//   dlogp/dbeta_0 = S1/s^2, dlogp/dw = G/s^2, dlogp/ds = -n/s + S2/s^3.
+// All kernels write raw sums [row_block][chain][S2, S1, G_0..G_{d-1}] into the
+// workspace; linreg_finalize adds the blocks in fixed order in double.
+#include "bvi_common.h"
+
+int bvi_launch_linreg_bf16x3(const float* X, const float* y, int64_t n, int d, const float* theta, int c,
+                             float* ws, int* nb_out, hipStream_t s);
+int bvi_linreg_bf16x3_blocks(int64_t n, int c);
+
+// ---------------------------------------------------------------------------
+// d <= 8: VALU kernel, lane = chain + CP * row-subset (see normal_iid.hip).
+// ---------------------------------------------------------------------------
+template <int DP, int CP>
+__global__ __launch_bounds__(256) void linreg_valu_kernel(const float* __restrict__ X,
+                                                          const float* __restrict__ y, int64_t n, int d,
+                                                          const float* __restrict__ theta, int C,
+                                                          float* __restrict__ partials) {
+  constexpr int RS = 64 / CP;
+  constexpr int Q = DP + 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = lane & (CP - 1), rsub = lane / CP;
+  const int chain = blockIdx.y * CP + cl;
+  float b0 = 0.f, w[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) w[j] = 0.f;
+  if (chain < C) {
+    const float* th = theta + (int64_t)chain * (d + 2);
+    b0 = th[0];
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+      if (j < d) w[j] = th[1 + j];
+  }
+  float tot[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) tot[q] = 0.f;
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t i = t * 64 + lane;
+    const bool ok = i < n;
+    const float yv = ok ? y[i] : 0.f;
+    float xv[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) xv[j] = (ok && j < d) ? X[i * d + j] : 0.f;
+    const bool full = t * 64 + 64 <= n;
+    float acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < CP; ++j) {
+      const int src = rsub + RS * j;
+      float r = __shfl(yv, src, 64) - b0;
+      float xj[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) {
+        xj[k] = __shfl(xv[k], src, 64);
+        r = fmaf(-w[k], xj[k], r);
+      }
+      r = (full || t * 64 + src < n) ? r : 0.f;
+      acc[0] = fmaf(r, r, acc[0]);
+      acc[1] += r;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) acc[2 + k] = fmaf(r, xj[k], acc[2 + k]);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) tot[q] += acc[q];
+  }
+  __shared__ float sm[4][CP][Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const float v = bvi_reduce_over_rowsubs<CP>(tot[q]);
+    if (rsub == 0) sm[wave][cl][q] = v;
+  }
+  __syncthreads();
+  const int qreal = d + 2;
+  for (int idx = threadIdx.x; idx < CP * qreal; idx += 256) {
+    const int c = idx / qreal, q = idx - c * qreal;
+    const int gc = blockIdx.y * CP + c;
+    if (gc >= C) continue;
+    partials[((int64_t)blockIdx.x * C + gc) * qreal + q] = sm[0][c][q] + sm[1][c][q] + sm[2][c][q] + sm[3][c][q];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 8 < d <= 64: f32-input MFMA kernel (v_mfma_f32_16x16x4_f32: bitwise an f32
+// fma chain).  No LDS: each wave streams its own 16-row tiles straight into
+// the two operand layouts.
+//   GEMM1  R[16 rows, 16 chains] = (y - b0) - X W^T : A = X in "row" layout
+//          (lane (i = l&15, kq = l>>4) holds X[i][16m+4kq+e]), B = -W with the
+//          same feature permutation, 4*DT products of K = 4.
+//   GEMM2  G[16 chains, 64 feats] += R^T X : the GEMM1 accumulator register j
+//          of lane (chain = l&15, kq) is R[row 4kq+j][chain], exactly the A
+//          operand of a K = 4 product over rows {4kq+j}; B = X in "column"
+//          layout (lane (kq, nn = l&15) holds X[4kq+j][4nn+e]), 16 products.
+//          Output tile e holds features 4nn+e in column nn.
+// A wave owns NC chain tiles of 16; the chain group is the fastest-varying
+// part of the block index so that blocks sharing rows run together.
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ X, int64_t row, int col, int d, int64_t n) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row < n) {
+    const float* p = X + row * d + col;
+    if (VEC) {
+      if (col + 4 <= d) v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < d) v[e] = p[e];
+    }
+  }
+  return v;
+}
+
+template <int DT, int NC, bool VEC>
+__global__ __launch_bounds__(256) void linreg_f32_kernel(const float* __restrict__ X,
+                                                         const float* __restrict__ y, int64_t n, int d,
+                                                         const float* __restrict__ theta, int C, int ncg,
+                                                         float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int cg = blockIdx.x % ncg, rb = blockIdx.x / ncg, nrb = gridDim.x / ncg;
+  const int cb = cg * 16 * NC;
+
+  float wf[NC][DT][4], b0[NC];
+#pragma unroll
+  for (int t = 0; t < NC; ++t) {
+    const int chain = cb + 16 * t + li;
+    const bool ok = chain < C;
+    const float* th = theta + (int64_t)(ok ? chain : 0) * (d + 2);
+    b0[t] = ok ? th[0] : 0.f;
+#pragma unroll
+    for (int m = 0; m < DT; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = 16 * m + 4 * kq + e;
+        wf[t][m][e] = (ok && f < d) ? -th[1 + f] : 0.f;
+      }
+  }
+  f32x4 g[NC][4];
+  float s1[NC], s2[NC];
+#pragma unroll
+  for (int t = 0; t < NC; ++t) {
+    s1[t] = 0.f;
+    s2[t] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[t][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int64_t ntiles = (n + 15) / 16;
+  const int64_t stride = (int64_t)nrb * 4;
+  int64_t t0 = (int64_t)rb * 4 + wave;
+  f32x4 xa[DT], xb[4], yv;
+  auto load_tile = [&](int64_t tile, f32x4 (&a)[DT], f32x4 (&b)[4], f32x4& yy) {
+    const int64_t r0 = tile * 16;
+#pragma unroll
+    for (int m = 0; m < DT; ++m) a[m] = ld4<VEC>(X, r0 + li, 16 * m + 4 * kq, d, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = ld4<VEC>(X, r0 + 4 * kq + j, 4 * li, d, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yy[j] = (r0 + 4 * kq + j < n) ? y[r0 + 4 * kq + j] : 0.f;
+  };
+  if (t0 < ntiles) load_tile(t0, xa, xb, yv);
+  for (; t0 < ntiles; t0 += stride) {
+    f32x4 xa_n[DT], xb_n[4], yv_n;
+    const int64_t tn = t0 + stride;
+    if (tn < ntiles) load_tile(tn, xa_n, xb_n, yv_n);
+    const int64_t r0 = t0 * 16;
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+      f32x4 z;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] = (r0 + 4 * kq + j < n) ? yv[j] - b0[t] : 0.f;
+#pragma unroll
+      for (int m = 0; m < DT; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[m][e], wf[t][m][e], z, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s1[t] += z[j];
+        s2[t] = fmaf(z[j], z[j], s2[t]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[j], xb[j][e], g[t][e], 0, 0, 0);
+    }
+    if (tn < ntiles) {
+#pragma unroll
+      for (int m = 0; m < DT; ++m) xa[m] = xa_n[m];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xb[j] = xb_n[j];
+      yv = yv_n;
+    }
+  }
+
+  // cross-wave reduction through LDS, then one partial per (row block, chain)
+  const int qreal = d + 2;
+  __shared__ float sm[16 * NC][66];
+  // waves add their tiles one after another: fixed order, so bitwise reproducible
+  for (int turn = 0; turn < 4; ++turn) {
+    if (wave == turn) {
+#pragma unroll
+      for (int t = 0; t < NC; ++t) {
+        // S1/S2: lane (chain li, kq) holds the sum over its rows; add the 4 kq groups
+        float a = s1[t], b = s2[t];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (kq == 0) {
+          sm[16 * t + li][0] = (turn ? sm[16 * t + li][0] : 0.f) + b;
+          sm[16 * t + li][1] = (turn ? sm[16 * t + li][1] : 0.f) + a;
+        }
+        // G tile e: row (chain) 4kq + j, column nn = li  <->  feature 4 li + e
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float* p = &sm[16 * t + 4 * kq + j][2 + 4 * li + e];
+            *p = (turn ? *p : 0.f) + g[t][e][j];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < 16 * NC * qreal; idx += 256) {
+    const int c = idx / qreal, q = idx - c * qreal;
+    const int gc = cb + c;
+    if (gc >= C) continue;
+    partials[((int64_t)rb * C + gc) * qreal + q] = sm[c][q];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: fixed-order reduction over row blocks (double) + scaling.
+// One thread per (chain, raw-sum index).
+// ---------------------------------------------------------------------------
+__global__ void linreg_finalize(const float* __restrict__ partials, int nb, int64_t n, int d,
+                                const float* __restrict__ theta, int C, float* __restrict__ logp,
+                                float* __restrict__ grad) {
+  const int q2 = d + 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * q2) return;
+  const int c = idx / q2, q = idx - c * q2;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += (double)partials[((int64_t)b * C + c) * q2 + q];
+  const double sc = (double)theta[(int64_t)c * q2 + d + 1];
+  const double inv2 = 1.0 / (sc * sc), nn = (double)n;
+  if (q == 0) {
+    logp[c] = (float)(-0.5 * s * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
+    if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s * inv2 / sc);
+  } else if (grad) {
+    grad[(int64_t)c * q2 + (q - 1)] = (float)(s * inv2);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launch policy
+// ---------------------------------------------------------------------------
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int linreg_valu_blocks(int64_t n) { return clampi(bvi_ceil_div(n, 256), 1, BVI_MAX_ROW_BLOCKS); }
+static int linreg_f32_nc(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : 4); }
+static int linreg_f32_blocks(int64_t n, int c) {
+  const int ncg = bvi_ceil_div(c, 16 * linreg_f32_nc(c));
+  // 64 rows per workgroup pass; aim at ~8 workgroups per CU in flight overall
+  return clampi(bvi_ceil_div(n, 64), 1, clampi(2048 / ncg, 1, BVI_MAX_ROW_BLOCKS));
+}
+static bool use_bf16x3(int d, int c, int prec) {
+  if (prec == BVI_PREC_F32) return false;
+  const bool shape_ok = (d == 32 || d == 64);
+  if (prec == BVI_PREC_BF16X3) return shape_ok;
+  return shape_ok && c >= 128;
+}
+
+size_t bvi_ws_linreg(int64_t n, int c, int d) {
+  int nb = d <= 8 ? linreg_valu_blocks(n) : linreg_f32_blocks(n, c);
+  if (d == 32 || d == 64) {
+    const int nb2 = bvi_linreg_bf16x3_blocks(n, c);
+    nb = nb2 > nb ? nb2 : nb;
+  }
+  return (size_t)nb * c * (d + 2) * sizeof(float);
+}
+
+template <int DP>
+static void linreg_valu_dispatch(int cp, dim3 grid, hipStream_t s, const float* X, const float* y, int64_t n,
+                                 int d, const float* theta, int c, float* ws) {
+  switch (cp) {
+    case 1: hipLaunchKernelGGL((linreg_valu_kernel<DP, 1>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ws); break;
+    case 4: hipLaunchKernelGGL((linreg_valu_kernel<DP, 4>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ws); break;
+    case 16: hipLaunchKernelGGL((linreg_valu_kernel<DP, 16>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ws); break;
+    default: hipLaunchKernelGGL((linreg_valu_kernel<DP, 64>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ws); break;
+  }
+}
+
+template <int DT, bool VEC>
+static void linreg_f32_dispatch(int nc, dim3 grid, hipStream_t s, const float* X, const float* y, int64_t n, int d,
+                                const float* theta, int c, int ncg, float* ws) {
+  switch (nc) {
+    case 1: hipLaunchKernelGGL((linreg_f32_kernel<DT, 1, VEC>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ncg, ws); break;
+    case 2: hipLaunchKernelGGL((linreg_f32_kernel<DT, 2, VEC>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ncg, ws); break;
+    default: hipLaunchKernelGGL((linreg_f32_kernel<DT, 4, VEC>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ncg, ws); break;
+  }
+}
+
+int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
+                      float* logp, float* grad, float* ws, hipStream_t s) {
+  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+  if (prec == BVI_PREC_BF16X3 && !use_bf16x3(d, c, prec)) return BVI_ERR_UNSUPPORTED;
+  int nb;
+  if (use_bf16x3(d, c, prec)) {
+    const int st = bvi_launch_linreg_bf16x3(X, y, n, d, theta, c, ws, &nb, s);
+    if (st != BVI_OK) return st;
+  } else if (d <= 8) {
+    nb = linreg_valu_blocks(n);
+    const int cp = bvi_chain_pack(c);
+    dim3 grid(nb, bvi_ceil_div(c, cp));
+    if (d == 1) linreg_valu_dispatch<1>(cp, grid, s, X, y, n, d, theta, c, ws);
+    else if (d == 2) linreg_valu_dispatch<2>(cp, grid, s, X, y, n, d, theta, c, ws);
+    else if (d <= 4) linreg_valu_dispatch<4>(cp, grid, s, X, y, n, d, theta, c, ws);
+    else linreg_valu_dispatch<8>(cp, grid, s, X, y, n, d, theta, c, ws);
+    BVI_HIP_CHECK_LAUNCH();
+  } else {
+    const int nc = linreg_f32_nc(c);
+    const int ncg = bvi_ceil_div(c, 16 * nc);
+    nb = linreg_f32_blocks(n, c);
+    dim3 grid(nb * ncg);
+    const int dt = bvi_ceil_div(d, 16);
+    const bool vec = (d % 4 == 0) && (((uintptr_t)X & 15) == 0);
+#define BVI_F32_CASE(DT)                                                                        \
+  case DT:                                                                                      \
+    if (vec) linreg_f32_dispatch<DT, true>(nc, grid, s, X, y, n, d, theta, c, ncg, ws);         \
+    else linreg_f32_dispatch<DT, false>(nc, grid, s, X, y, n, d, theta, c, ncg, ws);            \
+    break;
+    switch (dt) {
+      BVI_F32_CASE(1)
+      BVI_F32_CASE(2)
+      BVI_F32_CASE(3)
+      BVI_F32_CASE(4)
+    }
+#undef BVI_F32_CASE
+    BVI_HIP_CHECK_LAUNCH();
+  }
+  const int tot = c * (d + 2);
+  hipLaunchKernelGGL(linreg_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws, nb, n, d,
+                     theta, c, logp, grad);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}

@@ -1,0 +1,99 @@
+/*
+ * bvi.h -- C ABI of libbvi_hip.so: the MI355X (gfx950) implementation of the
+ * bayes_vi data-parallel hot path, the batched log-likelihood and its gradient
+ * for all chains at once.
+ *
+ * The reference (bayes_vi 0.3.0) has no FFI: its boundary is the Python closure
+ *     target_log_prob(state) = joint.log_prob(**params, y=targets)
+ * built at bayes_vi/inference/mcmc/mcmc.py:57-62 and bayes_vi/inference/vi/vi.py:46-52
+ * and evaluated (value and autodiff gradient) by TensorFlow-Probability inside
+ * every HMC/NUTS leapfrog step and every Monte-Carlo ELBO gradient.  Each entry
+ * point below replaces the data-dependent part of that closure for one
+ * likelihood family; the citation on each names the reference construct it
+ * stands in for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - nothing here allocates, frees or synchronises: scratch memory comes in
+ *     through `ws` (size from bvi_workspace_bytes) and results are ready when
+ *     `stream` reaches the end of the enqueued work;
+ *   - return value: 0 = success, > 0 = a hipError_t, < 0 = BVI_ERR_*;
+ *   - outputs are LIKELIHOOD-ONLY sums over the rows handed in:
+ *         logp[c]    = sum_{i < n} log p(y_i | theta_c, x_i)
+ *         grad[c, :] = d logp[c] / d theta_c          (constrained space)
+ *     so partial results of row shards add up (one all-reduce across GPUs);
+ *     priors and bijector Jacobians are added once by the caller;
+ *   - `theta` is [n_chains, P] row-major float32 in the flat parameter order of
+ *     the reference (param_names order, each part row-major flattened:
+ *     bayes_vi/inference/mcmc/mcmc.py:83-99, bayes_vi/model/model.py:123-153);
+ *   - `grad` may be NULL: value only (RandomWalkMetropolis,
+ *     bayes_vi/inference/mcmc/transition_kernels.py:319-321);
+ *   - non-finite parameters give non-finite outputs, never an error: the
+ *     sampler turns them into rejections as the reference does.
+ */
+#ifndef BVI_H
+#define BVI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVI_VERSION 100
+
+#define BVI_OK 0
+#define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
+#define BVI_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels cover         */
+#define BVI_ERR_WORKSPACE (-3)    /* ws is NULL or smaller than bvi_workspace_bytes */
+
+/* likelihood families */
+#define BVI_FAMILY_NORMAL_IID 0   /* tfd.Sample(tfd.Normal(loc, scale), N)              README.md:114-120 */
+#define BVI_FAMILY_LINREG 1       /* tfd.Normal(beta_0 + X w, scale)                    README.md:747-756 */
+#define BVI_FAMILY_GMM1D 2        /* MixtureSameFamily(Categorical(probs), Normal)      univariate-gaussian-mixture-test.ipynb cell 15 */
+#define BVI_FAMILY_GMM_FULLCOV 3  /* MixtureSameFamily(Categorical, MultivariateNormalTriL)  ...density-estimation-test.ipynb cell 7 */
+
+/* arithmetic of the chains x features x rows contraction (linear regression) */
+#define BVI_PREC_AUTO 0           /* F32 below 128 chains, BF16X3 from there on (needs d % 16 == 0, d <= 64) */
+#define BVI_PREC_F32 1            /* exact f32 (f32-input MFMA / VALU fma chains)                  */
+#define BVI_PREC_BF16X3 2         /* bf16 hi/lo split, 3 MFMA products, f32 accumulate (~2^-17 per product) */
+
+int bvi_version(void);
+
+/* Human-readable text for a status returned by any entry point (host pointer,
+ * static storage). */
+const char* bvi_status_string(int status);
+
+/* Bytes of device scratch the entry point of `family` needs for this shape.
+ * d = features (LINREG) or dimensions (GMM_FULLCOV), k = mixture components;
+ * pass 0 for the ones the family does not use. */
+int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, size_t* out_bytes);
+
+/* iid Normal likelihood: y[n], theta[C,2] = (loc, scale) -> logp[C], grad[C,2].
+ * Replaces JointDistributionNamedAutoBatched.log_prob of the 'y' node built by
+ * bayes_vi/model/model.py:17-21,197-203 for README.md:119-120, and its gradient
+ * taken by tfp.mcmc kernels (transition_kernels.py:122-128, 238-246). */
+int bvi_normal_iid_logp_grad(const float* y, int64_t n, const float* theta, int n_chains,
+                             float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+/* Gaussian linear regression: X[n,d] row-major, y[n],
+ * theta[C,d+2] = (beta_0, w_1..w_d, scale) -> logp[C], grad[C,d+2].
+ * Replaces the feature-conditioned likelihood node of bayes_vi/model/model.py:194-195,
+ * 201-203 for README.md:754-756 (features as one [N,D] tensor, utils/datasets.py:48-50). */
+int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta,
+                         int n_chains, int precision, float* logp, float* grad,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* Univariate Gaussian mixture: y[n], theta[C,3k] = (weights_k, loc_k, scale_k)
+ * -> logp[C], grad[C,3k].  Weights are normalised by their sum, as
+ * Categorical(probs=weights) does.  Replaces the likelihood node for
+ * exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15. */
+int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains,
+                        float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVI_H */

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path, called through the C ABI (ctypes), against the fp64
+closed-form oracle on the same seeded inputs and against the golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import closed_form as cf
+from parity_util import assert_grad_close, assert_logp_close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def nat(gpu_device):
+    from bayes_vi_amd import _native
+    _native.lib()
+    return _native
+
+
+@pytest.fixture(scope='module')
+def ws(nat, gpu_device):
+    return nat.Workspace(gpu_device)
+
+
+def dev(a, device):
+    return torch.tensor(np.asarray(a, np.float32), device=device)
+
+
+def test_golden_vectors(nat, ws, gpu_device):
+    with open(os.path.join(ROOT, 'tests', 'golden', 'hotpath_small.json')) as f:
+        cases = json.load(f)['cases']
+    for case in cases:
+        th = dev(case['theta'], gpu_device); y = dev(case['y'], gpu_device)
+        if case['family'] == 'normal_iid':
+            lp, g = nat.normal_iid_logp_grad(y, th, ws)
+        elif case['family'] == 'linreg':
+            lp, g = nat.linreg_logp_grad(dev(case['X'], gpu_device), y, th, ws)
+        else:
+            lp, g = nat.gmm1d_logp_grad(y, th, case['k'], ws)
+        assert_logp_close(lp.cpu().numpy(), case['logp'])
+        assert_grad_close(g.cpu().numpy(), case['grad'])
+
+
+@pytest.mark.parametrize('c,n', [(1, 1), (2, 20), (5, 100), (3, 1000), (64, 4096), (130, 10007), (17, 300001)])
+def test_normal_iid(nat, ws, gpu_device, c, n):
+    rng = np.random.default_rng(100 + c + n)
+    y = rng.normal(7, 3, n).astype(np.float32)
+    th = np.stack([rng.normal(7, 0.5, c), rng.uniform(2, 4, c)], -1).astype(np.float32)
+    ref_lp, ref_g = cf.normal_iid(y, th)
+    lp, g = nat.normal_iid_logp_grad(dev(y, gpu_device), dev(th, gpu_device), ws)
+    r = np.abs(y[None] - th[:, :1]); sc = th[:, 1:2].astype(np.float64)
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=np.stack([(r / sc ** 2).sum(-1), (r * r / sc[:, :1] ** 3).sum(-1) + n / sc[:, 0]], -1))
+    lp2, g2 = nat.normal_iid_logp_grad(dev(y, gpu_device), dev(th, gpu_device), ws, want_grad=False)
+    assert g2 is None
+    np.testing.assert_array_equal(lp2.cpu().numpy(), lp.cpu().numpy())
+
+
+def test_normal_iid_empty(nat, ws, gpu_device):
+    th = dev([[1.0, 2.0], [0.5, 1.5]], gpu_device)
+    lp, g = nat.normal_iid_logp_grad(torch.empty(0, device=gpu_device), th, ws)
+    np.testing.assert_array_equal(lp.cpu().numpy(), [0.0, 0.0])
+    np.testing.assert_array_equal(g.cpu().numpy(), np.zeros((2, 2)))
+
+
+def _linreg_case(rng, n, d, c, spread=0.05):
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    w = rng.normal(size=d)
+    y = (0.5 + X @ w + rng.normal(size=n)).astype(np.float32)
+    th = np.concatenate([0.5 + spread * rng.normal(size=(c, 1)), w + spread * rng.normal(size=(c, d)),
+                         rng.uniform(0.8, 1.5, (c, 1))], -1).astype(np.float32)
+    return X, y, th
+
+
+def _linreg_term_scale(X, y, th):
+    d = X.shape[1]
+    X64, y64, th64 = X.astype(np.float64), y.astype(np.float64), th.astype(np.float64)
+    r = np.abs(y64[None] - th64[:, :1] - th64[:, 1:1 + d] @ X64.T)
+    s2 = th64[:, -1:] ** 2
+    gs = np.concatenate([r.sum(-1, keepdims=True), r @ np.abs(X64),
+                         (r * r).sum(-1, keepdims=True) / th64[:, -1:] + len(y) * th64[:, -1:]], -1) / s2
+    return gs
+
+
+@pytest.mark.parametrize('d,c,n', [(1, 2, 50), (1, 1, 1), (2, 5, 100), (3, 16, 777), (5, 33, 4096), (8, 64, 1000),
+                                   (8, 100, 20011), (12, 4, 500), (16, 16, 1024), (31, 7, 333), (32, 33, 2048),
+                                   (33, 5, 100), (48, 64, 4099), (64, 2, 20), (64, 100, 8192), (64, 17, 100003)])
+def test_linreg_f32(nat, ws, gpu_device, d, c, n):
+    rng = np.random.default_rng(7 * d + c + n)
+    X, y, th = _linreg_case(rng, n, d, c)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws,
+                                 precision=nat.PREC_F32)
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th))
+
+
+@pytest.mark.parametrize('d,c,n', [(64, 128, 64), (64, 256, 1000), (64, 300, 4096 + 17), (32, 128, 5000),
+                                   (64, 1024, 20000), (32, 513, 777), (64, 32, 300)])
+def test_linreg_bf16x3(nat, ws, gpu_device, d, c, n):
+    rng = np.random.default_rng(11 * d + c + n)
+    X, y, th = _linreg_case(rng, n, d, c)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws,
+                                 precision=nat.PREC_BF16X3)
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th))
+    # AUTO must pick the same kernel from 128 chains on, the exact-f32 one below
+    lp_a, g_a = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws)
+    if c >= 128:
+        np.testing.assert_array_equal(lp_a.cpu().numpy(), lp.cpu().numpy())
+        np.testing.assert_array_equal(g_a.cpu().numpy(), g.cpu().numpy())
+
+
+def test_linreg_deterministic(nat, ws, gpu_device):
+    rng = np.random.default_rng(5)
+    X, y, th = _linreg_case(rng, 30000, 64, 256)
+    args = (dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device))
+    a = nat.linreg_logp_grad(*args, ws)
+    b = nat.linreg_logp_grad(*args, ws)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_linreg_errors(nat, ws, gpu_device):
+    X = torch.zeros(10, 65, device=gpu_device); y = torch.zeros(10, device=gpu_device)
+    th = torch.ones(2, 67, device=gpu_device)
+    with pytest.raises(nat.BviError):
+        nat.linreg_logp_grad(X, y, th, ws)
+    X = torch.zeros(10, 16, device=gpu_device); th = torch.ones(2, 18, device=gpu_device)
+    with pytest.raises(nat.BviError):
+        nat.linreg_logp_grad(X, y, th, ws, precision=nat.PREC_BF16X3)
+    with pytest.raises(nat.BviError):
+        nat.linreg_logp_grad(X.cpu(), y, th, ws)
+
+
+def test_nonfinite_parameters_propagate(nat, ws, gpu_device):
+    y = dev(np.linspace(-1, 1, 100), gpu_device)
+    th = dev([[0.0, -1.0], [float('nan'), 1.0], [0.0, 1.0]], gpu_device)
+    lp, g = nat.normal_iid_logp_grad(y, th, ws)
+    lp = lp.cpu().numpy()
+    assert not np.isfinite(lp[0]) and not np.isfinite(lp[1]) and np.isfinite(lp[2])
+
+
+@pytest.mark.parametrize('k,c,n', [(1, 1, 10), (2, 4, 100), (3, 5, 999), (5, 2, 64), (8, 4, 4096), (8, 64, 3000),
+                                   (8, 70, 20001), (16, 3, 500), (4, 16, 100000)])
+def test_gmm1d(nat, ws, gpu_device, k, c, n):
+    rng = np.random.default_rng(13 * k + c + n)
+    locs = np.linspace(-20, 20, k) if k > 1 else np.array([1.0])
+    scs = 1.0 + (np.arange(k) % 3)
+    comp = rng.integers(0, k, n)
+    y = rng.normal(locs[comp], scs[comp]).astype(np.float32)
+    th = np.concatenate([rng.dirichlet(np.ones(k) * 5, c) * rng.uniform(0.5, 2.0, (c, 1)),
+                         locs + rng.normal(0, .5, (c, k)), scs * rng.uniform(0.8, 1.2, (c, k))], -1).astype(np.float32)
+    ref_lp, ref_g = cf.gmm1d(y, th, k)
+    lp, g = nat.gmm1d_logp_grad(dev(y, gpu_device), dev(th, gpu_device), k, ws)
+    # scale of the summed terms: every row contributes O(1/s), O(1/w) sized terms
+    ts = np.concatenate([n / th[:, :k], n / th[:, 2 * k:] * np.ones((c, k)), 3 * n / th[:, 2 * k:]], -1) * 0.3
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=ts)

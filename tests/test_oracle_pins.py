@@ -227,27 +227,26 @@ def test_restated_torch_matches_closed_form():
 
 
 def test_sufficient_statistic_posterior_table():
-    """univariate_gaussian_experiment/tables: NUTS posterior sd of loc ~ s/sqrt(N)
-    and of scale ~ s/sqrt(2N) for N = 100 (dataset_infos.txt:6-15 vs
-    mcmc_summary_statistics.txt:6-25, skipping the stuck-chain datasets 5 and 7).
-    Checked here against a Laplace approximation of the oracle's posterior."""
+    """univariate_gaussian_experiment/tables: NUTS posterior mean / sd for N = 100
+    (dataset_infos.txt:6-15 vs mcmc_summary_statistics.txt:6-25, skipping the
+    stuck-chain datasets 5 and 7).  The posterior depends on the data only
+    through (N, sample loc, sample scale); its moments are computed here by
+    quadrature of the oracle's log posterior on a grid and must reproduce the
+    table to its two printed decimals (table inputs are themselves rounded)."""
     table = {1: (3.37, 1.65, 3.37, 0.16, 1.68, 0.12), 2: (-2.03, 2.45, -2.03, 0.25, 2.49, 0.18),
              4: (4.59, 3.69, 4.59, 0.38, 3.76, 0.27), 9: (13.94, 1.82, 13.94, 0.18, 1.85, 0.13)}
     for _, (m, s, pm, psd, sm, ssd) in table.items():
         rng = np.random.default_rng(8)
         y = rng.normal(size=100); y = (y - y.mean()) / y.std(ddof=1) * s + m
         model = cf.normal_model(y)
-        # numeric Hessian of the constrained log posterior at its mode
-        th = np.array([[m, s]])
-        for _ in range(50):
-            _, g = model.log_post_constrained(th)
-            H = np.zeros((2, 2))
-            for j in range(2):
-                e = np.zeros((1, 2)); e[0, j] = 1e-5
-                H[:, j] = (model.log_post_constrained(th + e)[1] - model.log_post_constrained(th - e)[1])[0] / 2e-5
-            th = th - np.linalg.solve(H, g[0])[None]
-        cov = np.linalg.inv(-H)
-        assert th[0, 0] == pytest.approx(pm, abs=0.02)
-        assert math.sqrt(cov[0, 0]) == pytest.approx(psd, abs=0.015)
-        assert th[0, 1] == pytest.approx(sm, abs=0.06)       # mode < mean for the skewed scale posterior
-        assert math.sqrt(cov[1, 1]) == pytest.approx(ssd, abs=0.015)
+        locs = np.linspace(m - 8 * s / 10, m + 8 * s / 10, 201)
+        scs = np.linspace(s * 0.6, s * 1.8, 241)
+        L, S = np.meshgrid(locs, scs, indexing='ij')
+        lp, _ = model.log_post_constrained(np.stack([L.ravel(), S.ravel()], -1))
+        w = np.exp(lp - lp.max()).reshape(L.shape); w /= w.sum()
+        mean_loc = (w * L).sum(); sd_loc = math.sqrt((w * (L - mean_loc) ** 2).sum())
+        mean_sc = (w * S).sum(); sd_sc = math.sqrt((w * (S - mean_sc) ** 2).sum())
+        assert mean_loc == pytest.approx(pm, abs=0.015)
+        assert sd_loc == pytest.approx(psd, abs=0.015)
+        assert mean_sc == pytest.approx(sm, abs=0.03)
+        assert sd_sc == pytest.approx(ssd, abs=0.015)
