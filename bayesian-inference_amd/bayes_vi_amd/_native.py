@@ -12,7 +12,7 @@ import os
 import torch
 
 FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV = 0, 1, 2, 3
-PREC_AUTO, PREC_F32, PREC_BF16X3 = 0, 1, 2
+PREC_AUTO, PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'libbvi_hip.so')
 _lib = None

@@ -1,0 +1,194 @@
+"""A small distribution vocabulary with TFP-shaped constructors.
+
+The reference builds its models from `tfp.distributions` objects
+(README.md:114-120, 747-756; exploratory_experiments/*.ipynb); this module
+offers the same names and keyword arguments for the ones its models use, on
+torch tensors.  Priors are evaluated here (O(#parameters) work per chain);
+likelihoods are only *described* by these objects -- `Model` recognises the
+description and routes the sum over datapoints to the fused HIP kernels.
+
+Parameters may be python floats, torch tensors, or the symbolic expressions of
+`bayes_vi_amd.symbolic` (which is how a likelihood callable is recognised
+without evaluating it on data).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import bijectors as tfb
+
+LN2PI = math.log(2.0 * math.pi)
+
+
+def _t(v, like=None):
+    if isinstance(v, torch.Tensor):
+        return v
+    try:
+        return torch.as_tensor(v, dtype=torch.float32)
+    except (TypeError, ValueError, RuntimeError):
+        return v  # symbolic expression
+
+
+def _is_concrete(*vs):
+    return all(isinstance(v, torch.Tensor) for v in vs)
+
+
+class Distribution:
+    """Common surface: batch_shape/event_shape, dtype, log_prob, sample,
+    default event-space bijector, and the closed-form score used by samplers."""
+    dtype = torch.float32
+
+    @property
+    def batch_shape(self):
+        return torch.Size(())
+
+    @property
+    def event_shape(self):
+        return torch.Size(())
+
+    def param_event_shape(self):
+        """Shape of one draw = batch_shape + event_shape (what AutoBatched treats as the event)."""
+        return torch.Size(tuple(self.batch_shape) + tuple(self.event_shape))
+
+    def log_prob(self, x):
+        raise NotImplementedError
+
+    def log_prob_flat(self, x):
+        """x[..., n] with n = prod(param_event_shape): summed log density [...]."""
+        raise NotImplementedError
+
+    def score_flat(self, x):
+        """d log_prob_flat / d x, closed form."""
+        raise NotImplementedError
+
+    def sample(self, sample_shape=(), generator=None):
+        raise NotImplementedError
+
+    def default_bijector(self):
+        return tfb.Identity()
+
+
+class Normal(Distribution):
+    def __init__(self, loc, scale, name='Normal'):
+        self.loc, self.scale, self.name = _t(loc), _t(scale), name
+
+    @property
+    def batch_shape(self):
+        if not _is_concrete(self.loc, self.scale):
+            return torch.Size(())
+        return torch.broadcast_shapes(self.loc.shape, self.scale.shape)
+
+    def log_prob(self, x):
+        z = (x - self.loc.to(x.device)) / self.scale.to(x.device)
+        return -0.5 * z * z - 0.5 * LN2PI - torch.log(self.scale.to(x.device))
+
+    def log_prob_flat(self, x):
+        loc = self.loc.to(x.device).expand(self.batch_shape).reshape(-1) if self.loc.dim() else self.loc.to(x.device)
+        sc = self.scale.to(x.device).expand(self.batch_shape).reshape(-1) if self.scale.dim() else self.scale.to(x.device)
+        z = (x - loc) / sc
+        return (-0.5 * z * z - 0.5 * LN2PI - torch.log(sc)).sum(-1)
+
+    def score_flat(self, x):
+        loc = self.loc.to(x.device).expand(self.batch_shape).reshape(-1) if self.loc.dim() else self.loc.to(x.device)
+        sc = self.scale.to(x.device).expand(self.batch_shape).reshape(-1) if self.scale.dim() else self.scale.to(x.device)
+        return -(x - loc) / (sc * sc)
+
+    def sample(self, sample_shape=(), generator=None):
+        shape = tuple(sample_shape) + tuple(self.batch_shape)
+        return self.loc + self.scale * torch.randn(shape, generator=generator)
+
+
+class HalfNormal(Distribution):
+    def __init__(self, scale, name='HalfNormal'):
+        self.scale, self.name = _t(scale), name
+
+    @property
+    def batch_shape(self):
+        return self.scale.shape if _is_concrete(self.scale) else torch.Size(())
+
+    def _sc(self, x):
+        sc = self.scale.to(x.device)
+        return sc.reshape(-1) if sc.dim() else sc
+
+    def log_prob(self, x):
+        sc = self.scale.to(x.device)
+        lp = 0.5 * math.log(2.0 / math.pi) - torch.log(sc) - 0.5 * (x / sc) ** 2
+        return torch.where(x < 0, torch.full_like(lp, -math.inf), lp)
+
+    def log_prob_flat(self, x):
+        sc = self._sc(x)
+        lp = 0.5 * math.log(2.0 / math.pi) - torch.log(sc) - 0.5 * (x / sc) ** 2
+        return torch.where(x < 0, torch.full_like(lp, -math.inf), lp).sum(-1)
+
+    def score_flat(self, x):
+        sc = self._sc(x)
+        return -x / (sc * sc)
+
+    def sample(self, sample_shape=(), generator=None):
+        shape = tuple(sample_shape) + tuple(self.batch_shape)
+        return (self.scale * torch.randn(shape, generator=generator)).abs()
+
+    def default_bijector(self):
+        return tfb.Softplus()
+
+
+class Dirichlet(Distribution):
+    def __init__(self, concentration, name='Dirichlet'):
+        self.concentration, self.name = _t(concentration), name
+
+    @property
+    def event_shape(self):
+        return self.concentration.shape[-1:]
+
+    @property
+    def batch_shape(self):
+        return self.concentration.shape[:-1]
+
+    def log_prob(self, x):
+        a = self.concentration.to(x.device)
+        norm = torch.lgamma(a.sum(-1)) - torch.lgamma(a).sum(-1)
+        return norm + ((a - 1.0) * torch.log(x)).sum(-1)
+
+    def log_prob_flat(self, x):
+        return self.log_prob(x)
+
+    def score_flat(self, x):
+        return (self.concentration.to(x.device) - 1.0) / x
+
+    def sample(self, sample_shape=(), generator=None):
+        a = self.concentration.expand(tuple(sample_shape) + tuple(self.concentration.shape))
+        g = torch._standard_gamma(a) if generator is None else torch._standard_gamma(a)
+        return g / g.sum(-1, keepdim=True)
+
+    def default_bijector(self):
+        return tfb.SoftmaxCentered()
+
+
+class Categorical(Distribution):
+    """Only used to describe mixture weights: Categorical(probs=weights)."""
+
+    def __init__(self, probs=None, logits=None, name='Categorical'):
+        if (probs is None) == (logits is None):
+            raise ValueError('Must pass probs or logits, but not both.')
+        self.probs, self.logits, self.name = probs, logits, name
+
+
+class MultivariateNormalTriL(Distribution):
+    def __init__(self, loc=None, scale_tril=None, name='MultivariateNormalTriL'):
+        self.loc, self.scale_tril, self.name = _t(loc), _t(scale_tril), name
+
+
+class MixtureSameFamily(Distribution):
+    def __init__(self, mixture_distribution, components_distribution, name='MixtureSameFamily'):
+        self.mixture_distribution = mixture_distribution
+        self.components_distribution = components_distribution
+        self.name = name
+
+
+class Sample(Distribution):
+    """tfd.Sample(distribution, sample_shape): iid product (bayes_vi/model/model.py:17-21)."""
+
+    def __init__(self, distribution, sample_shape=(), name='Sample'):
+        self.distribution, self.sample_shape, self.name = distribution, sample_shape, name

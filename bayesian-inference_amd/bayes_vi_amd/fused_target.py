@@ -1,0 +1,192 @@
+"""The drop-in for the reference's `target_log_prob` closure.
+
+In the reference, `MCMC.__init__` (bayes_vi/inference/mcmc/mcmc.py:52-62) and
+`VI.__init__` (bayes_vi/inference/vi/vi.py:40-52) capture the whole dataset as
+one batch and build `target_log_prob(state) = joint.log_prob(**state, y=targets)`;
+TFP then evaluates that closure and its autodiff gradient for all chains at
+every leapfrog step / ELBO sample.  Here the same quantity is split into
+
+  * `FusedLogLikelihood`: sum over the (local shard of) datapoints of the
+    log-likelihood and its gradient for all chains, one fused HIP pass through
+    the C ABI (`_native`), all-reduced over the row shards of a process group;
+  * `Posterior`: + log-priors and, in unconstrained space, the bijector chain
+    rule and forward-log-det-Jacobian terms -- O(chains x parameters) torch ops
+    added once, after the reduction.
+
+There is no CPU path: tensors must live on a GPU and libbvi_hip.so must load.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _native
+from .bijectors import Blockwise
+
+
+class FusedLogLikelihood:
+    """Base: value and gradient of sum_i log p(y_i | theta_c, x_i) for all chains c.
+
+    `group`: a torch.distributed process group whose ranks each hold a disjoint
+    row shard of the dataset; the [C, 1+P] partial sums are all-reduced over it
+    (RCCL on GPUs).  `None` = single shard.
+    """
+    family = None
+    n_params = None
+
+    def __init__(self, device, group=None):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _native.BviError('the fused log-likelihood runs on MI355X only; got device %s' % device)
+        _native.lib()
+        self.ws = _native.Workspace(self.device)
+        self.group = group
+        self.sharded = group is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def _call(self, theta, logp, grad):
+        raise NotImplementedError
+
+    def logp_grad(self, theta, want_grad=True):
+        """theta[C, P] float32 (constrained) -> (logp[C], grad[C, P] or None), summed over ALL shards."""
+        theta = theta.contiguous()
+        c = theta.shape[0]
+        # one flat buffer so that the shard reduction is a single collective
+        buf = torch.empty(c * (1 + (self.n_params if want_grad else 0)), dtype=torch.float32, device=theta.device)
+        logp = buf[:c]
+        grad = buf[c:].view(c, self.n_params) if want_grad else None
+        self._call(theta, logp, grad)
+        if self.sharded:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return logp, grad
+
+
+def _launch(fn, *args):
+    _native.check(fn(*args), fn.__name__)
+
+
+class NormalIID(FusedLogLikelihood):
+    """y_i ~ Normal(loc, scale) iid; theta = (loc, scale).  README.md:114-120."""
+    family = _native.FAMILY_NORMAL_IID
+    n_params = 2
+
+    def __init__(self, y, group=None):
+        super().__init__(y.device, group)
+        self.y = y.to(torch.float32).contiguous().reshape(-1)
+        self.n = self.y.shape[0]
+
+    def _call(self, theta, logp, grad):
+        c = theta.shape[0]
+        buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c))
+        _launch(_native.lib().bvi_normal_iid_logp_grad, _native._ptr(self.y), self.n, _native._ptr(theta), c,
+                _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(), _native._stream())
+
+
+class LinearRegression(FusedLogLikelihood):
+    """y_i ~ Normal(beta_0 + x_i . w, scale); theta = (beta_0, w[D], scale).  README.md:747-756."""
+    family = _native.FAMILY_LINREG
+
+    def __init__(self, X, y, group=None, precision=_native.PREC_AUTO):
+        super().__init__(X.device, group)
+        self.X = X.to(torch.float32).contiguous()
+        if self.X.dim() == 1:
+            self.X = self.X[:, None]
+        self.y = y.to(torch.float32).contiguous().reshape(-1)
+        self.n, self.d = self.X.shape
+        self.n_params = self.d + 2
+        self.precision = precision
+
+    def _call(self, theta, logp, grad):
+        c = theta.shape[0]
+        buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d))
+        _launch(_native.lib().bvi_linreg_logp_grad, _native._ptr(self.X), _native._ptr(self.y), self.n, self.d,
+                _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), _native._ptr(buf),
+                buf.numel(), _native._stream())
+
+
+class GaussianMixture1D(FusedLogLikelihood):
+    """y_i ~ sum_k w_k Normal(loc_k, scale_k); theta = (weights[K], loc[K], scale[K]).
+    exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15."""
+    family = _native.FAMILY_GMM1D
+
+    def __init__(self, y, k, group=None):
+        super().__init__(y.device, group)
+        self.y = y.to(torch.float32).contiguous().reshape(-1)
+        self.n, self.k = self.y.shape[0], int(k)
+        self.n_params = 3 * self.k
+
+    def _call(self, theta, logp, grad):
+        c = theta.shape[0]
+        buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, k=self.k))
+        _launch(_native.lib().bvi_gmm1d_logp_grad, _native._ptr(self.y), self.n, self.k, _native._ptr(theta), c,
+                _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(), _native._stream())
+
+
+class Posterior:
+    """log pi(theta) = log-likelihood (fused) + sum of log-priors, in constrained
+    and unconstrained coordinates.
+
+    priors: list of (distribution, flat_size) in parameter order; bijectors: one
+    per prior (forward = constrain).  Flat layouts follow the reference
+    (param_names order, each part row-major flattened: mcmc.py:83-99).
+    """
+
+    def __init__(self, likelihood: FusedLogLikelihood, priors, bijectors):
+        self.likelihood = likelihood
+        self.priors = [p for p, _ in priors]
+        self.csizes = [int(s) for _, s in priors]
+        self.usizes = [b.inverse_event_size(s) for b, s in zip(bijectors, self.csizes)]
+        self.bijector = Blockwise(bijectors, self.usizes)
+        self.n_constrained = sum(self.csizes)
+        self.n_unconstrained = sum(self.usizes)
+        if self.n_constrained != likelihood.n_params:
+            raise ValueError('priors describe %d parameters, the likelihood takes %d'
+                             % (self.n_constrained, likelihood.n_params))
+
+    # ---- constrained space: the closure of mcmc.py:57-62 / vi.py:46-52 ----
+    def log_prior(self, theta, want_grad=True):
+        parts = torch.split(theta, self.csizes, dim=-1)
+        lp = sum(p.log_prob_flat(x) for p, x in zip(self.priors, parts))
+        g = torch.cat([p.score_flat(x) for p, x in zip(self.priors, parts)], -1) if want_grad else None
+        return lp, g
+
+    def log_prob_and_grad(self, theta, want_grad=True):
+        ll, gl = self.likelihood.logp_grad(theta, want_grad)
+        lp, gp = self.log_prior(theta, want_grad)
+        return ll + lp, (gl + gp if want_grad else None)
+
+    def log_prob(self, theta):
+        return self.log_prob_and_grad(theta, want_grad=False)[0]
+
+    # ---- unconstrained space: what TransformedTransitionKernel evaluates (mcmc.py:153-156) ----
+    def unconstrained_log_prob_and_grad(self, z, want_grad=True):
+        theta = self.bijector.forward(z)
+        lp, g = self.log_prob_and_grad(theta, want_grad)
+        lp = lp + self.bijector.forward_log_det_jacobian(z)
+        if not want_grad:
+            return lp, None
+        return lp, self.bijector.vjp(z, g) + self.bijector.grad_fldj(z)
+
+    def unconstrained_log_prob(self, z):
+        return self.unconstrained_log_prob_and_grad(z, want_grad=False)[0]
+
+
+class _TargetLogProbFn(torch.autograd.Function):
+    """Makes the fused pass one autograd node: forward computes log pi AND keeps
+    d log pi / d theta from the same data pass, backward is an O(S x P) product.
+    (The reference's GradientTape re-traverses the [S, N] graph: vi.py:66-69.)"""
+
+    @staticmethod
+    def forward(ctx, theta, posterior):
+        lp, g = posterior.log_prob_and_grad(theta.detach(), want_grad=True)
+        ctx.save_for_backward(g)
+        return lp
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g, = ctx.saved_tensors
+        return grad_out[:, None] * g, None
+
+
+def differentiable_log_prob(posterior: Posterior, theta):
+    """Constrained log pi(theta) for theta[S, P], differentiable by torch autograd."""
+    return _TargetLogProbFn.apply(theta, posterior)

@@ -43,7 +43,7 @@ int bvi_normal_iid_logp_grad(const float* y, int64_t n, const float* theta, int 
 int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta, int n_chains,
                          int precision, float* logp, float* grad, void* ws, size_t ws_bytes, void* stream) {
   if (((!X || !y) && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
-  if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X3) return BVI_ERR_ARG;
+  if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X6) return BVI_ERR_ARG;
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_linreg(n, n_chains, d)) return BVI_ERR_WORKSPACE;
   return bvi_launch_linreg(X, y, n, d, theta, n_chains, precision, logp, grad, (float*)ws, (hipStream_t)stream);

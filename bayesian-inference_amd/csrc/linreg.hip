@@ -15,7 +15,7 @@
 #include "bvi_common.h"
 
 int bvi_launch_linreg_bf16x3(const float* X, const float* y, int64_t n, int d, const float* theta, int c,
-                             float* ws, int* nb_out, hipStream_t s);
+                             int pieces, float* ws, int* nb_out, hipStream_t s);
 int bvi_linreg_bf16x3_blocks(int64_t n, int c);
 
 // ---------------------------------------------------------------------------
@@ -274,11 +274,14 @@ static int linreg_f32_blocks(int64_t n, int c) {
   // 64 rows per workgroup pass; aim at ~8 workgroups per CU in flight overall
   return clampi(bvi_ceil_div(n, 64), 1, clampi(2048 / ncg, 1, BVI_MAX_ROW_BLOCKS));
 }
-static bool use_bf16x3(int d, int c, int prec) {
+// AUTO takes the bf16-split kernel only where the contraction dominates and the
+// row count is large enough that its ~2^-17 per-product rounding averages out
+// well below 1e-5 of the sums (the error of a sum of n terms falls as 1/sqrt(n)).
+static bool use_bf16x3(int64_t n, int d, int c, int prec) {
   if (prec == BVI_PREC_F32) return false;
   const bool shape_ok = (d == 32 || d == 64);
-  if (prec == BVI_PREC_BF16X3) return shape_ok;
-  return shape_ok && c >= 128;
+  if (prec == BVI_PREC_BF16X3 || prec == BVI_PREC_BF16X6) return shape_ok;
+  return shape_ok && c >= 128 && n >= 16384;
 }
 
 size_t bvi_ws_linreg(int64_t n, int c, int d) {
@@ -314,10 +317,10 @@ static void linreg_f32_dispatch(int nc, dim3 grid, hipStream_t s, const float* X
 int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
                       float* logp, float* grad, float* ws, hipStream_t s) {
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
-  if (prec == BVI_PREC_BF16X3 && !use_bf16x3(d, c, prec)) return BVI_ERR_UNSUPPORTED;
+  if ((prec == BVI_PREC_BF16X3 || prec == BVI_PREC_BF16X6) && !use_bf16x3(n, d, c, prec)) return BVI_ERR_UNSUPPORTED;
   int nb;
-  if (use_bf16x3(d, c, prec)) {
-    const int st = bvi_launch_linreg_bf16x3(X, y, n, d, theta, c, ws, &nb, s);
+  if (use_bf16x3(n, d, c, prec)) {
+    const int st = bvi_launch_linreg_bf16x3(X, y, n, d, theta, c, prec == BVI_PREC_BF16X3 ? 2 : 3, ws, &nb, s);
     if (st != BVI_OK) return st;
   } else if (d <= 8) {
     nb = linreg_valu_blocks(n);

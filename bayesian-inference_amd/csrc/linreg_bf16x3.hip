@@ -1,7 +1,11 @@
 // Linear-regression raw sums (S2, S1, G) for many chains on the bf16 matrix
-// cores with a hi/lo split: every f32 operand v is carried as
-// hi = bf16(v), lo = bf16(v - hi) and every product as hi*hi + lo*hi + hi*lo
-// (f32 accumulate), i.e. ~2^-17 relative per product instead of bf16's 2^-9.
+// cores with split operands: every f32 operand v is carried as bf16 pieces
+// p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1) and a product as the
+// sum of piece products, f32 accumulate:
+//   2 pieces, 3 products (p0p0 + p1p0 + p0p1):            ~2^-18 relative per product
+//   3 pieces, 6 products (+ p1p1 + p2p0 + p0p2):          ~2^-24, i.e. f32 grade
+// The residual GEMM (X W^T, whose result cancels against y) takes NP pieces
+// (template: 2 or 3); the gradient GEMM (R^T X) always takes 2.
 // This is the chains x features x rows contraction of the likelihood node
 // tfd.Normal(beta_0 + X w, scale) (bayes_vi/model/model.py:194-203,
 // README.md:754-756) and of its gradient, fused so that the [chains, rows]
@@ -39,7 +43,21 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
   }
 }
 
-template <int D>
+template <int NP>
+__device__ __forceinline__ void splitn(const float* v, bf16x8 (&p)[NP]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float rem = v[j];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const __bf16 h = (__bf16)rem;
+      p[i][j] = h;
+      rem -= (float)h;
+    }
+  }
+}
+
+template <int D, int NP>
 __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __restrict__ X,
                                                                  const float* __restrict__ y, int64_t n,
                                                                  const float* __restrict__ theta, int C,
@@ -49,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __
   constexpr int NT = D / 32;        // 32-feature output tiles of GEMM2
   constexpr int SA = 2 * D + 16;    // LDS row stride in bytes (16-B pad: conflict-free ds_read_b128)
   constexpr int IMG = kTileRows * SA;
-  constexpr int BUF = 2 * IMG + kTileRows * 4;
+  constexpr int BUF = NP * IMG + kTileRows * 4;
   constexpr int TPR = D / 8;        // staging threads per row
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
@@ -63,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __
   const bool cvalid = chain < C;
 
   // -W fragments (B operand of GEMM1) and b0, resident for the whole kernel
-  bf16x8 wh[KS], wl[KS];
+  bf16x8 wp[KS][NP];
   float b0 = 0.f;
   {
     const float* th = theta + (int64_t)(cvalid ? chain : 0) * (D + 2);
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = cvalid ? -th[1 + 16 * ks + 8 * h + j] : 0.f;
-      split8(v, wh[ks], wl[ks]);
+      splitn<NP>(v, wp[ks]);
     }
   }
 
@@ -109,12 +127,12 @@ __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __
   auto lstore = [&](int buf) {
     unsigned char* base = lds + buf * BUF;
     if (sact) {
-      bf16x8 hi, lo;
-      split8(xr, hi, lo);
-      *reinterpret_cast<bf16x8*>(base + srow * SA + scol * 2) = hi;
-      *reinterpret_cast<bf16x8*>(base + IMG + srow * SA + scol * 2) = lo;
+      bf16x8 xp[NP];
+      splitn<NP>(xr, xp);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) *reinterpret_cast<bf16x8*>(base + i * IMG + srow * SA + scol * 2) = xp[i];
     }
-    if (tid < kTileRows) reinterpret_cast<float*>(base + 2 * IMG)[tid] = yr;
+    if (tid < kTileRows) reinterpret_cast<float*>(base + NP * IMG)[tid] = yr;
   };
 
   int64_t tile = rbi;
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __
     if (tnext < ntiles) gload(tnext);
 
     const unsigned char* base = lds + buf * BUF;
-    const float* yb = reinterpret_cast<const float*>(base + 2 * IMG);
+    const float* yb = reinterpret_cast<const float*>(base + NP * IMG);
     const bool full = tile * kTileRows + kTileRows <= n;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -151,11 +169,15 @@ __global__ __launch_bounds__(kThreads) void linreg_bf16x3_kernel(const float* __
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (32 * st + r) * SA + (16 * ks + 8 * h) * 2;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + off);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + IMG + off);
-        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[ks], z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[ks], z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[ks], z, 0, 0, 0);
+        bf16x8 a[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) a[i] = *reinterpret_cast<const bf16x8*>(base + i * IMG + off);
+        // piece products of total order <= NP-1 (piece i carries ~2^-8i of the value)
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+          for (int j = 0; j + i < NP; ++j)
+            z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], wp[ks][j], z, 0, 0, 0);
       }
       // ---- S1, S2 and the bf16 split of R ----
       float a1 = 0.f, a2 = 0.f;
@@ -235,16 +257,20 @@ int bvi_linreg_bf16x3_blocks(int64_t n, int c) {
 }
 
 int bvi_launch_linreg_bf16x3(const float* X, const float* y, int64_t n, int d, const float* theta, int c,
-                             float* ws, int* nb_out, hipStream_t s) {
+                             int pieces, float* ws, int* nb_out, hipStream_t s) {
   if (((uintptr_t)X & 15) != 0) return BVI_ERR_ARG;
   int ncb, nrb;
   bf16x3_grid(c, &ncb, &nrb);
   *nb_out = nrb;
   dim3 grid(ncb * nrb);
-  if (d == 64)
-    hipLaunchKernelGGL(linreg_bf16x3_kernel<64>, grid, dim3(kThreads), 0, s, X, y, n, theta, c, ncb, nrb, ws);
-  else if (d == 32)
-    hipLaunchKernelGGL(linreg_bf16x3_kernel<32>, grid, dim3(kThreads), 0, s, X, y, n, theta, c, ncb, nrb, ws);
+  if (d == 64 && pieces == 2)
+    hipLaunchKernelGGL((linreg_bf16x3_kernel<64, 2>), grid, dim3(kThreads), 0, s, X, y, n, theta, c, ncb, nrb, ws);
+  else if (d == 64 && pieces == 3)
+    hipLaunchKernelGGL((linreg_bf16x3_kernel<64, 3>), grid, dim3(kThreads), 0, s, X, y, n, theta, c, ncb, nrb, ws);
+  else if (d == 32 && pieces == 2)
+    hipLaunchKernelGGL((linreg_bf16x3_kernel<32, 2>), grid, dim3(kThreads), 0, s, X, y, n, theta, c, ncb, nrb, ws);
+  else if (d == 32 && pieces == 3)
+    hipLaunchKernelGGL((linreg_bf16x3_kernel<32, 3>), grid, dim3(kThreads), 0, s, X, y, n, theta, c, ncb, nrb, ws);
   else
     return BVI_ERR_UNSUPPORTED;
   BVI_HIP_CHECK_LAUNCH();

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog gradient evaluations per second (chains x steps)
+of Bayesian linear regression at N = 10M rows, D = 64 features, 1024 chains
+(BASELINE.json configs[1]) on MI355X.
+
+A "step" is one leapfrog step of every chain: momentum half-step, position
+step, ONE fused pass of the hot path over the whole (row-sharded) dataset --
+log-likelihood and gradient for all chains through the C ABI, all-reduced over
+the ranks, plus priors and the bijector chain rule -- and the second momentum
+half-step.  With --gpus N (launched under torch.distributed.run) the rows are
+split over the ranks, chains stay replicated, and every step does one RCCL
+all-reduce of the [chains, 1+P] partial sums: strong scaling of a fixed dataset.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def make_shard(n_local, d, rank, device):
+    """Synthetic regression shard: X ~ N(0,1), y = 0.5 + X w* + N(0,1); w* is common to all ranks."""
+    g = torch.Generator(device=device); g.manual_seed(1000 + rank)
+    gw = torch.Generator(device='cpu'); gw.manual_seed(1)
+    w_true = torch.randn(d, generator=gw).to(device)
+    X = torch.empty(n_local, d, dtype=torch.float32, device=device)
+    step = 1 << 20
+    for s in range(0, n_local, step):          # chunked so the generator never needs a second 2.5 GB buffer
+        X[s:s + step].normal_(generator=g)
+    y = 0.5 + X @ w_true + torch.randn(n_local, generator=g, device=device)
+    return X, y, w_true
+
+
+def cpu_baseline(n_total, d, seconds_budget=20.0):
+    """Restated TFP-equivalent CPU path (oracle/restated_torch.py) on a bounded sample,
+    scaled to the full row count.  Reported only; never a gate."""
+    from oracle import restated_torch as rt
+    c_s, n_s, chunk = 32, 200_000, 50_000
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(n_s, d, generator=g); w = torch.randn(d, generator=g)
+    y = 0.5 + X @ w + torch.randn(n_s, generator=g)
+    theta = torch.cat([0.5 + 0.01 * torch.randn(c_s, 1, generator=g), w + 0.01 * torch.randn(c_s, d, generator=g),
+                       1.0 + 0.01 * torch.randn(c_s, 1, generator=g).abs()], -1)
+    rt.linreg(X, y, theta, chunk=chunk)        # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t_start) < seconds_budget:
+        t0 = time.perf_counter()
+        rt.linreg(X, y, theta, chunk=chunk)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    t = times[len(times) // 2]
+    value = c_s / (t * (n_total / n_s))        # chain-steps per second at the full row count
+    return {
+        'value': value, 'unit': 'grad-evals/s (chains x steps) at N=%d' % n_total,
+        'cores': torch.get_num_threads(), 'kind': 'port',
+        'sample': ('restated TFP-equivalent torch-CPU fp32 path (materialised [C,N] ops + autograd), '
+                   '%d chains x %d rows x D=%d in chunks of %d rows, median of %d runs of %.2f s, '
+                   'scaled linearly to N=%d rows' % (c_s, n_s, d, chunk, len(times), t, n_total)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--rows', type=int, default=10_000_000)
+    ap.add_argument('--features', type=int, default=64)
+    ap.add_argument('--chains', type=int, default=1024)
+    ap.add_argument('--step-size', type=float, default=1e-4)
+    ap.add_argument('--precision', default='auto', choices=['auto', 'f32', 'bf16x3', 'bf16x6'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
+                             % (args.gpus, args.gpus))
+        args.gpus = world
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    group = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        group = dist.group.WORLD
+
+    from bayes_vi_amd import _native, distributions as tfd, bijectors as tfb
+    from bayes_vi_amd.fused_target import LinearRegression, Posterior
+
+    n, d, c = args.rows, args.features, args.chains
+    n_local = n // world + (1 if rank < n % world else 0)
+    X, y, w_true = make_shard(n_local, d, rank, device)
+    prec = {'auto': _native.PREC_AUTO, 'f32': _native.PREC_F32, 'bf16x3': _native.PREC_BF16X3,
+            'bf16x6': _native.PREC_BF16X6}[args.precision]
+    lik = LinearRegression(X, y, group=group, precision=prec)
+    post = Posterior(lik,
+                     [(tfd.Normal(0., 10.), 1), (tfd.Normal(torch.zeros(d), 10.), d), (tfd.HalfNormal(10.), 1)],
+                     [tfb.Identity(), tfb.Identity(), tfb.Softplus()])
+
+    # chains start near the posterior mode (w* + 0.01 N(0,1)): residuals O(1), as in a running sampler
+    g0 = torch.Generator(device='cpu'); g0.manual_seed(2)
+    theta0 = torch.cat([0.5 + 0.01 * torch.randn(c, 1, generator=g0),
+                        w_true.cpu() + 0.01 * torch.randn(c, d, generator=g0),
+                        1.0 + 0.01 * torch.randn(c, 1, generator=g0).abs()], -1).to(device)
+    z = post.bijector.inverse(theta0)
+    g3 = torch.Generator(device='cpu'); g3.manual_seed(3)
+    p = torch.randn(c, post.n_unconstrained, generator=g3).to(device)
+    eps = args.step_size
+
+    kernel_events = []
+
+    def value_and_grad(zz, timed):
+        # Posterior.unconstrained_log_prob_and_grad, with HIP events bracketing the fused
+        # likelihood pass on the stream it is launched on (torch's current stream)
+        theta = post.bijector.forward(zz)
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        buf = torch.empty(c * (1 + lik.n_params), dtype=torch.float32, device=device)
+        logp, grad = buf[:c], buf[c:].view(c, lik.n_params)
+        lik._call(theta.contiguous(), logp, grad)
+        if timed:
+            e1.record(); kernel_events.append((e0, e1))
+        if lik.sharded:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        lp_prior, g_prior = post.log_prior(theta)
+        lp = logp + lp_prior + post.bijector.forward_log_det_jacobian(zz)
+        gz = post.bijector.vjp(zz, grad + g_prior) + post.bijector.grad_fldj(zz)
+        return lp, gz
+
+    lp, g = value_and_grad(z, False)
+
+    def leapfrog_step(z, p, g, timed):
+        p = p + 0.5 * eps * g
+        z = z + eps * p
+        lp, g = value_and_grad(z, timed)
+        p = p + 0.5 * eps * g
+        return z, p, g, lp
+
+    for _ in range(args.warmup):
+        z, p, g, lp = leapfrog_step(z, p, g, False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        z, p, g, lp = leapfrog_step(z, p, g, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(lp).all().item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    flops = 4.0 * c * n_local * d
+    alg_bytes = 4.0 * n_local * (d + 1) + 8.0 * c * (d + 2)
+    uses_bf16 = args.precision in ('auto', 'bf16x3', 'bf16x6') and c >= 128 and n_local >= 16384 and d in (32, 64)
+    peak = MFMA_BF16_PEAK_TFLOPS if uses_bf16 else MFMA_F32_PEAK_TFLOPS
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    out = {
+        'metric': 'leapfrog grad-evals/sec (chains x steps) at N=10M, D=64; % of HBM roofline',
+        'value': c * args.steps / elapsed,
+        'unit': 'grad-evals/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': 'f32 (bf16 3-piece split MFMA, f32 accumulate)' if uses_bf16 else 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'Bayesian linear regression, HMC leapfrog gradient evaluations (BASELINE configs[1])',
+                   'rows': n, 'rows_per_gpu': n_local, 'features': d, 'chains': c, 'precision': args.precision,
+                   'parallelism': 'rows sharded over %d GPU(s), chains replicated, all-reduce of [C,1+P] per step' % world},
+        'roofline': {
+            'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+            'traffic': None,
+            'kernel': 'linreg_bf16x3_kernel<64,3>' if uses_bf16 else 'linreg_f32_kernel',
+            'kernel_ms': kern_ms, 'algorithmic_flops_per_launch': flops,
+            'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'achieved_GBps': alg_bytes / (kern_ms * 1e-3) / 1e9,
+                    'peak_GBps': HBM_PEAK_GBPS, 'frac': alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        },
+        'finite': finite,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(n, d)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -56,9 +56,11 @@ extern "C" {
 #define BVI_FAMILY_GMM_FULLCOV 3  /* MixtureSameFamily(Categorical, MultivariateNormalTriL)  ...density-estimation-test.ipynb cell 7 */
 
 /* arithmetic of the chains x features x rows contraction (linear regression) */
-#define BVI_PREC_AUTO 0           /* F32 below 128 chains, BF16X3 from there on (needs d % 16 == 0, d <= 64) */
-#define BVI_PREC_F32 1            /* exact f32 (f32-input MFMA / VALU fma chains)                  */
-#define BVI_PREC_BF16X3 2         /* bf16 hi/lo split, 3 MFMA products, f32 accumulate (~2^-17 per product) */
+#define BVI_PREC_AUTO 0           /* BF16X6 when n_chains >= 128, n >= 16384 and d is 32 or 64; else F32 */
+#define BVI_PREC_F32 1            /* exact f32 (f32-input MFMA / VALU fma chains)                      */
+#define BVI_PREC_BF16X3 2         /* bf16 2-piece split, 3 MFMA products per GEMM (~2^-18 per product) */
+#define BVI_PREC_BF16X6 3         /* bf16 3-piece split (6 products, f32 grade) for the residual GEMM,
+                                     2-piece (3 products) for the gradient GEMM                        */
 
 int bvi_version(void);
 

@@ -100,20 +100,37 @@ def test_linreg_f32(nat, ws, gpu_device, d, c, n):
 
 
 @pytest.mark.parametrize('d,c,n', [(64, 128, 64), (64, 256, 1000), (64, 300, 4096 + 17), (32, 128, 5000),
-                                   (64, 1024, 20000), (32, 513, 777), (64, 32, 300)])
-def test_linreg_bf16x3(nat, ws, gpu_device, d, c, n):
+                                   (64, 1024, 20000), (32, 513, 777), (64, 32, 300), (64, 130, 200000)])
+def test_linreg_bf16_split(nat, ws, gpu_device, d, c, n):
+    """BF16X6 (3-piece residual GEMM, 2-piece gradient GEMM) must meet the 1e-5 bar
+    like the exact-f32 kernels; AUTO selects it from 128 chains and 16384 rows on."""
+    rng = np.random.default_rng(11 * d + c + n)
+    X, y, th = _linreg_case(rng, n, d, c, spread=0.05 if n < 100000 else 0.005)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    args = (dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device))
+    lp, g = nat.linreg_logp_grad(*args, ws, precision=nat.PREC_BF16X6)
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th))
+    lp_a, g_a = nat.linreg_logp_grad(*args, ws)
+    lp_f, g_f = nat.linreg_logp_grad(*args, ws, precision=nat.PREC_F32)
+    same_as = (lp, g) if (c >= 128 and n >= 16384) else (lp_f, g_f)
+    np.testing.assert_array_equal(lp_a.cpu().numpy(), same_as[0].cpu().numpy())
+    np.testing.assert_array_equal(g_a.cpu().numpy(), same_as[1].cpu().numpy())
+
+
+@pytest.mark.parametrize('d,c,n', [(64, 128, 5000), (32, 256, 20000)])
+def test_linreg_bf16x3_reduced_precision(nat, ws, gpu_device, d, c, n):
+    """BF16X3 (2-piece split in both GEMMs) is the documented reduced-precision mode:
+    ~2^-18 per product leaves the residuals good to ~1e-5 absolute, so logp still meets
+    1e-5 but the gradient, a cancelling sum, is only good to ~1e-3 of its largest entry.
+    It is never selected by AUTO."""
     rng = np.random.default_rng(11 * d + c + n)
     X, y, th = _linreg_case(rng, n, d, c)
     ref_lp, ref_g = cf.linreg(X, y, th)
     lp, g = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws,
                                  precision=nat.PREC_BF16X3)
     assert_logp_close(lp.cpu().numpy(), ref_lp)
-    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th))
-    # AUTO must pick the same kernel from 128 chains on, the exact-f32 one below
-    lp_a, g_a = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws)
-    if c >= 128:
-        np.testing.assert_array_equal(lp_a.cpu().numpy(), lp.cpu().numpy())
-        np.testing.assert_array_equal(g_a.cpu().numpy(), g.cpu().numpy())
+    assert_grad_close(g.cpu().numpy(), ref_g, rtol=2e-3)
 
 
 def test_linreg_deterministic(nat, ws, gpu_device):
@@ -132,7 +149,7 @@ def test_linreg_errors(nat, ws, gpu_device):
         nat.linreg_logp_grad(X, y, th, ws)
     X = torch.zeros(10, 16, device=gpu_device); th = torch.ones(2, 18, device=gpu_device)
     with pytest.raises(nat.BviError):
-        nat.linreg_logp_grad(X, y, th, ws, precision=nat.PREC_BF16X3)
+        nat.linreg_logp_grad(X, y, th, ws, precision=nat.PREC_BF16X6)
     with pytest.raises(nat.BviError):
         nat.linreg_logp_grad(X.cpu(), y, th, ws)
 
