@@ -43,8 +43,12 @@ def lib():
         l.bvi_normal_iid_logp_grad.argtypes = [vp, i64, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, sz, vp]
+        l.bvi_linreg_packed_bytes.argtypes = [i64, i32, ctypes.POINTER(sz)]
+        l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, vp, sz, vp]
+        l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
-                     'bvi_gmm1d_logp_grad'):
+                     'bvi_gmm1d_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack',
+                     'bvi_linreg_packed_logp_grad'):
             getattr(l, name).restype = i32
         _lib = l
     return _lib
@@ -130,4 +134,26 @@ def gmm1d_logp_grad(y, theta, k, ws: Workspace, want_grad=True):
     buf = ws.get(workspace_bytes(FAMILY_GMM1D, n, c, k=k))
     check(lib().bvi_gmm1d_logp_grad(_ptr(y), n, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
                                     buf.numel(), _stream()), 'bvi_gmm1d_logp_grad')
+    return logp, grad
+
+
+def linreg_pack(X, y):
+    """One-time split of (X, y) into the bf16 piece planes of the matrix-core kernel."""
+    _check_f32_cuda(X, y)
+    n, d = X.shape
+    out = ctypes.c_size_t(0)
+    check(lib().bvi_linreg_packed_bytes(n, d, ctypes.byref(out)), 'bvi_linreg_packed_bytes')
+    packed = torch.empty(max(int(out.value), 16), dtype=torch.uint8, device=X.device)
+    check(lib().bvi_linreg_pack(_ptr(X), _ptr(y), n, d, _ptr(packed), packed.numel(), _stream()), 'bvi_linreg_pack')
+    return packed
+
+
+def linreg_packed_logp_grad(packed, n, d, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO):
+    _check_f32_cuda(theta)
+    c = theta.shape[0]
+    assert theta.shape == (c, d + 2)
+    logp, grad = _outputs(theta, want_grad)
+    buf = ws.get(workspace_bytes(FAMILY_LINREG, n, c, d=d))
+    check(lib().bvi_linreg_packed_logp_grad(_ptr(packed), n, d, _ptr(theta), c, precision, _ptr(logp), _ptr(grad),
+                                            _ptr(buf), buf.numel(), _stream()), 'bvi_linreg_packed_logp_grad')
     return logp, grad

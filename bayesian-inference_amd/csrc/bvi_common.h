@@ -43,6 +43,10 @@ size_t bvi_ws_gmm1d(int64_t n, int c, int k);
 int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
                       float* logp, float* grad, float* ws, hipStream_t s);
 size_t bvi_ws_linreg(int64_t n, int c, int d);
+size_t bvi_linreg_packed_size(int64_t n, int d);
+int bvi_launch_linreg_pack(const float* X, const float* y, int64_t n, int d, void* packed, hipStream_t s);
+int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* theta, int c, int prec,
+                             float* logp, float* grad, float* ws, hipStream_t s);
 
 #ifdef __HIPCC__
 // Sum over the lanes that share (lane % CP): butterfly over the upper lane bits.

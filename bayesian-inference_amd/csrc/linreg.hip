@@ -14,8 +14,8 @@
 // workspace; linreg_finalize adds the blocks in fixed order in double.
 #include "bvi_common.h"
 
-int bvi_launch_linreg_bf16x3(const float* X, const float* y, int64_t n, int d, const float* theta, int c,
-                             int pieces, float* ws, int* nb_out, hipStream_t s);
+int bvi_launch_linreg_bf16x3(const float* X, const float* y, const void* packed, int64_t n, int d,
+                             const float* theta, int c, int pieces, float* ws, int* nb_out, hipStream_t s);
 int bvi_linreg_bf16x3_blocks(int64_t n, int c);
 
 // ---------------------------------------------------------------------------
@@ -314,13 +314,28 @@ static void linreg_f32_dispatch(int nc, dim3 grid, hipStream_t s, const float* X
   }
 }
 
+int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* theta, int c, int prec,
+                             float* logp, float* grad, float* ws, hipStream_t s) {
+  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (prec == BVI_PREC_F32) return BVI_ERR_UNSUPPORTED;
+  int nb;
+  const int st = bvi_launch_linreg_bf16x3(nullptr, nullptr, packed, n, d, theta, c, prec == BVI_PREC_BF16X3 ? 2 : 3,
+                                          ws, &nb, s);
+  if (st != BVI_OK) return st;
+  const int tot = c * (d + 2);
+  hipLaunchKernelGGL(linreg_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws, nb, n, d,
+                     theta, c, logp, grad);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
 int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
                       float* logp, float* grad, float* ws, hipStream_t s) {
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
   if ((prec == BVI_PREC_BF16X3 || prec == BVI_PREC_BF16X6) && !use_bf16x3(n, d, c, prec)) return BVI_ERR_UNSUPPORTED;
   int nb;
   if (use_bf16x3(n, d, c, prec)) {
-    const int st = bvi_launch_linreg_bf16x3(X, y, n, d, theta, c, prec == BVI_PREC_BF16X3 ? 2 : 3, ws, &nb, s);
+    const int st = bvi_launch_linreg_bf16x3(X, y, nullptr, n, d, theta, c, prec == BVI_PREC_BF16X3 ? 2 : 3, ws, &nb, s);
     if (st != BVI_OK) return st;
   } else if (d <= 8) {
     nb = linreg_valu_blocks(n);

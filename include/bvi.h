@@ -88,6 +88,20 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
                          int n_chains, int precision, float* logp, float* grad,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* The same likelihood on a dataset packed once for the bf16-split matrix-core kernel.
+ * The reference turns the dataset into two immutable full-batch tensors when the
+ * driver is constructed (bayes_vi/inference/mcmc/mcmc.py:52, vi/vi.py:40); packing is the
+ * MI355X form of that one-time step: X and y are split into bf16 pieces
+ * ([3][n_pad][d] planes + a 16-B row extension, n_pad = n rounded up to 64 with zero
+ * rows) so that the per-evaluation kernel stages tiles without any arithmetic.
+ * d must be 32 or 64; precision F32 is not available on packed data. */
+int bvi_linreg_packed_bytes(int64_t n, int d, size_t* out_bytes);
+int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, void* packed, size_t packed_bytes,
+                    void* stream);
+int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, const float* theta, int n_chains,
+                                int precision, float* logp, float* grad, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* Univariate Gaussian mixture: y[n], theta[C,3k] = (weights_k, loc_k, scale_k)
  * -> logp[C], grad[C,3k].  Weights are normalised by their sum, as
  * Categorical(probs=weights) does.  Replaces the likelihood node for

@@ -111,6 +111,11 @@ def test_linreg_bf16_split(nat, ws, gpu_device, d, c, n):
     lp, g = nat.linreg_logp_grad(*args, ws, precision=nat.PREC_BF16X6)
     assert_logp_close(lp.cpu().numpy(), ref_lp)
     assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th))
+    # the packed entry point runs the same arithmetic on a dataset split once up front
+    pk = nat.linreg_pack(args[0], args[1])
+    lp_p, g_p = nat.linreg_packed_logp_grad(pk, n, d, args[2], ws, precision=nat.PREC_BF16X6)
+    np.testing.assert_array_equal(lp_p.cpu().numpy(), lp.cpu().numpy())
+    np.testing.assert_array_equal(g_p.cpu().numpy(), g.cpu().numpy())
     lp_a, g_a = nat.linreg_logp_grad(*args, ws)
     lp_f, g_f = nat.linreg_logp_grad(*args, ws, precision=nat.PREC_F32)
     same_as = (lp, g) if (c >= 128 and n >= 16384) else (lp_f, g_f)
