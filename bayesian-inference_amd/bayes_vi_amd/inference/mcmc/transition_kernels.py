@@ -1,0 +1,83 @@
+"""Markov transition kernel configuration (mirror of
+bayes_vi/inference/mcmc/transition_kernels.py): same class names, constructor arguments,
+defaults and traced metrics.  Calling a kernel object with a target builds the batched
+kernel of `samplers` (the reference builds a functools.partial over tfp.mcmc.*)."""
+from . import samplers
+from .stepsize_adaptation_kernels import StepSizeAdaptationKernel
+
+
+class TransitionKernel:
+    """Base class for Markov transition kernels (transition_kernels.py:12-38)."""
+
+    def __init__(self, name=None):
+        self.name = name
+
+    def __str__(self):
+        return '%s(%s)' % (type(self).__name__, ', '.join('%s=%s' % item for item in vars(self).items()))
+
+    def _make(self, target):
+        raise NotImplementedError
+
+    def __call__(self, target_log_prob_fn):
+        """target_log_prob_fn(z, want_grad) -> (log_prob[C], grad[C, P] or None) in unconstrained space.
+        Returns (kernel, trace_metric_names)."""
+        if getattr(self, 'transforming_bijector', None) is not None:
+            raise NotImplementedError('transforming_bijector (trainable preconditioning) is not part of the '
+                                      'fused hot path')
+        kernel = self._make(target_log_prob_fn)
+        ada = getattr(self, 'stepsize_adaptation_kernel', None)
+        if isinstance(ada, StepSizeAdaptationKernel):
+            kernel = ada(kernel)
+        return kernel, list(self.trace_fn_metrics)
+
+
+class HamiltonianMonteCarlo(TransitionKernel):
+    """HMC (transition_kernels.py:41-137; defaults step_size=0.01, num_leapfrog_steps=5)."""
+
+    def __init__(self, step_size=0.01, num_leapfrog_steps=5, transforming_bijector=None,
+                 stepsize_adaptation_kernel=None, state_gradients_are_stopped=False, name=None):
+        super().__init__(name)
+        self.transforming_bijector = transforming_bijector
+        self.stepsize_adaptation_kernel = stepsize_adaptation_kernel
+        self.step_size = step_size
+        self.num_leapfrog_steps = num_leapfrog_steps
+        self.state_gradients_are_stopped = state_gradients_are_stopped
+        self.trace_fn_metrics = ['is_accepted', 'target_log_prob', 'step_size']
+
+    def _make(self, target):
+        return samplers.HamiltonianMonteCarloKernel(target, self.step_size, self.num_leapfrog_steps)
+
+
+class NoUTurnSampler(TransitionKernel):
+    """NUTS (transition_kernels.py:140-262; defaults step_size=0.01, max_tree_depth=5,
+    max_energy_diff=1000, unrolled_leapfrog_steps=1)."""
+
+    def __init__(self, step_size=0.01, max_tree_depth=5, max_energy_diff=1000.0, unrolled_leapfrog_steps=1,
+                 parallel_iterations=10, transforming_bijector=None, stepsize_adaptation_kernel=None, name=None):
+        super().__init__(name)
+        self.transforming_bijector = transforming_bijector
+        self.stepsize_adaptation_kernel = stepsize_adaptation_kernel
+        self.step_size = step_size
+        self.max_tree_depth = max_tree_depth
+        self.max_energy_diff = max_energy_diff
+        self.unrolled_leapfrog_steps = unrolled_leapfrog_steps
+        self.parallel_iterations = parallel_iterations
+        self.trace_fn_metrics = ['is_accepted', 'target_log_prob', 'log_accept_ratio', 'step_size',
+                                 'leapfrogs_taken', 'has_divergence', 'energy']
+
+    def _make(self, target):
+        return samplers.NoUTurnSamplerKernel(target, self.step_size, self.max_tree_depth, self.max_energy_diff,
+                                             self.unrolled_leapfrog_steps)
+
+
+class RandomWalkMetropolis(TransitionKernel):
+    """Random-walk Metropolis (transition_kernels.py:265-326); default proposal N(0, 1) per coordinate."""
+
+    def __init__(self, transforming_bijector=None, new_state_fn=None, name=None):
+        super().__init__(name)
+        self.transforming_bijector = transforming_bijector
+        self.new_state_fn = new_state_fn
+        self.trace_fn_metrics = ['is_accepted']
+
+    def _make(self, target):
+        return samplers.RandomWalkMetropolisKernel(target, new_state_fn=self.new_state_fn)
