@@ -1,0 +1,86 @@
+"""`VI`: variational inference (mirror of bayes_vi/inference/vi/vi.py)."""
+import numpy as np
+import torch
+
+from ...fused_target import differentiable_log_prob
+from ..inference import Inference
+
+
+def kl_reverse(logu):
+    """Reverse KL in log space: f(log u) = -log u (tfp.vi.kl_reverse)."""
+    return -logu
+
+
+class Adam:
+    """Optimizer description with the reference's spelling, tf.optimizers.Adam(learning_rate=...);
+    bound to the surrogate's parameters when `VI.fit` starts."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.betas, self.eps = learning_rate, (beta_1, beta_2), epsilon
+
+    def bind(self, params):
+        return torch.optim.Adam(params, lr=self.learning_rate, betas=self.betas, eps=self.eps)
+
+
+class VI(Inference):
+    """Same construction and `fit` signature as the reference (vi.py:37, 77-78).
+
+    The whole dataset is one batch on the GPU (vi.py:40); `target_log_prob` is the closure of
+    vi.py:46-52 on flat constrained samples [S, P(+extra)], evaluated -- value AND gradient in the
+    same pass -- by the fused kernels and exposed to autograd as a single node.
+    """
+
+    def __init__(self, model, dataset, surrogate_posterior, discrepancy_fn=kl_reverse, group=None, precision=None):
+        super().__init__(model=model, dataset=dataset)
+        self.features, self.targets = dataset.full_batch()
+        self.distribution = model.get_joint_distribution(num_samples=self.targets.shape[0], features=self.features,
+                                                         group=group, precision=precision)
+        self.posterior = self.distribution.posterior(self.targets)
+        self.device = self.posterior.likelihood.device
+        self.surrogate_posterior = surrogate_posterior.to(self.device)
+        p = self.model.flat_param_event_ndims
+        base = lambda sample: differentiable_log_prob(self.posterior, sample[:, :p].contiguous())
+        self.target_log_prob = self.surrogate_posterior.get_corrected_target_log_prob_fn(base)
+        self.discrepancy_fn = discrepancy_fn
+
+    def safe_discrepancy_fn(self, logu):
+        """Discrepancy with non-finite entries dropped before the mean (vi.py:55-58)."""
+        d = self.discrepancy_fn(logu)
+        return d[torch.isfinite(d)]
+
+    def loss(self, sample_size):
+        """Monte-Carlo variational loss with reparameterised samples
+        (tfp.vi.monte_carlo_variational_loss as called at vi.py:109-116)."""
+        q, logq = self.surrogate_posterior.sample_and_log_prob(sample_size)
+        logu = self.target_log_prob(q) - logq
+        return self.safe_discrepancy_fn(logu).mean()
+
+    def fit(self, optimizer=None, num_steps=10000, sample_size=1, num_samples_to_approx_marginals=10000,
+            progress_bar=True):
+        """Returns (approx_posterior, losses[num_steps]) (vi.py:77-127).  Every gradient is clipped
+        to norm 1 per variable, not globally (vi.py:70)."""
+        optimizer = optimizer if optimizer is not None else Adam()
+        params = [p for p in self.surrogate_posterior.parameters() if p.requires_grad]
+        opt = optimizer.bind(params) if hasattr(optimizer, 'bind') else optimizer(params)
+        losses = np.zeros(num_steps)
+        steps = range(num_steps)
+        if progress_bar:
+            try:
+                from tqdm import tqdm
+                steps = tqdm(steps, leave=False)
+            except Exception:
+                pass
+        for i in steps:
+            opt.zero_grad(set_to_none=True)
+            loss = self.loss(sample_size)
+            loss.backward()
+            for p in params:
+                if p.grad is not None:     # tf.clip_by_norm(grad, 1.0), without a host sync
+                    p.grad.mul_(torch.clamp(1.0 / (p.grad.norm() + 1e-30), max=1.0))
+            opt.step()
+            losses[i] = float(loss)
+        approx_posterior = self.surrogate_posterior.approx_joint_marginal_posteriors(num_samples_to_approx_marginals)
+        return approx_posterior, losses
+
+    def stochastic_fit(self, *args, **kwargs):
+        raise NotImplementedError('minibatch fitting is outside the fused full-batch hot path')

@@ -1,0 +1,197 @@
+"""GPU: the drop-in surface end to end -- Model / MCMC.fit / VI.fit over the fused kernels --
+against the fp64 oracle (posterior assembly) and against exact posterior moments (samplers)."""
+import collections
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import closed_form as cf
+from parity_util import assert_grad_close, assert_logp_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def bvi(gpu_device):
+    import bayes_vi_amd.distributions as tfd
+    from bayes_vi_amd.inference.mcmc import MCMC
+    from bayes_vi_amd.inference.mcmc.stepsize_adaptation_kernels import DualAveragingStepSizeAdaptation
+    from bayes_vi_amd.inference.mcmc.transition_kernels import (HamiltonianMonteCarlo, NoUTurnSampler,
+                                                                 RandomWalkMetropolis)
+    from bayes_vi_amd.inference.vi import VI
+    from bayes_vi_amd.inference.vi.surrogate_posteriors import ADVI, NormalizingFlow
+    from bayes_vi_amd.inference.vi.flow_bijectors import HamiltonianFlow
+    from bayes_vi_amd.inference.vi.vi import Adam
+    from bayes_vi_amd.model import Model
+    from bayes_vi_amd.utils.datasets import make_dataset_from_df
+    from bayes_vi_amd import symbolic
+    ns = dict(locals()); ns.pop('gpu_device')
+    return collections.namedtuple('bvi', ns.keys())(**ns)
+
+
+def normal_setup(bvi, y):
+    priors = collections.OrderedDict(loc=bvi.tfd.Normal(loc=0., scale=10.), scale=bvi.tfd.HalfNormal(scale=10.))
+    model = bvi.Model(priors=priors, likelihood=lambda loc, scale: bvi.tfd.Normal(loc=loc, scale=scale))
+    dataset = bvi.make_dataset_from_df(pd.DataFrame(dict(y=y)), target_names=['y'], format_features_as='dict')
+    return model, dataset
+
+
+def exact_normal_moments(y):
+    spec = cf.normal_model(y)
+    m, s = y.mean(), y.std(ddof=1)
+    L, S = np.meshgrid(np.linspace(m - 6 * s / math.sqrt(len(y)), m + 6 * s / math.sqrt(len(y)), 241),
+                       np.linspace(s * 0.35, s * 3.0, 401), indexing='ij')
+    lp, _ = spec.log_post_constrained(np.stack([L.ravel(), S.ravel()], -1))
+    w = np.exp(lp - lp.max()).reshape(L.shape); w /= w.sum()
+    ml, ms = (w * L).sum(), (w * S).sum()
+    return ml, math.sqrt((w * (L - ml) ** 2).sum()), ms, math.sqrt((w * (S - ms) ** 2).sum())
+
+
+def test_posterior_assembly_matches_oracle_all_families(bvi, gpu_device):
+    rng = np.random.default_rng(0)
+    # iid Normal (README.md:114-120)
+    y = rng.normal(7, 3, 20).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    post = bvi.MCMC(model, ds).posterior
+    z = rng.uniform(-1, 1, (6, 2)) + np.array([6.0, 1.5])
+    lp, g = post.unconstrained_log_prob_and_grad(torch.tensor(z, dtype=torch.float32, device=gpu_device))
+    rlp, rg = cf.normal_model(y).log_post_unconstrained(z.astype(np.float32))
+    assert_logp_close(lp.cpu().numpy(), rlp); assert_grad_close(g.cpu().numpy(), rg)
+    # regression with dict features (README.md:745-756)
+    x = rng.normal(0, 10, 50).astype(np.float32); yy = (7 + 3 * x + rng.normal(0, 10, 50)).astype(np.float32)
+    priors = collections.OrderedDict(beta_0=bvi.tfd.Normal(0., 10.), beta_1=bvi.tfd.Normal(0., 10.),
+                                     scale=bvi.tfd.HalfNormal(10.))
+
+    def likelihood(beta_0, beta_1, scale, features):
+        return bvi.tfd.Normal(loc=beta_0 + beta_1 * features['x'], scale=scale)
+    model = bvi.Model(priors, likelihood)
+    ds = bvi.make_dataset_from_df(pd.DataFrame(dict(x=x, y=yy)), target_names=['y'], feature_names=['x'])
+    post = bvi.MCMC(model, ds).posterior
+    z = rng.uniform(-1, 1, (5, 3)) + np.array([7.0, 3.0, 9.0])
+    lp, g = post.unconstrained_log_prob_and_grad(torch.tensor(z, dtype=torch.float32, device=gpu_device))
+    rlp, rg = cf.linreg_model(x[:, None], yy).log_post_unconstrained(z.astype(np.float32))
+    assert_logp_close(lp.cpu().numpy(), rlp); assert_grad_close(g.cpu().numpy(), rg)
+    # vector slopes via matvec, parameters declared in a different order than the kernel's
+    d = 16
+    X = rng.normal(size=(3000, d)).astype(np.float32); w = rng.normal(size=d)
+    y3 = (0.5 + X @ w + rng.normal(size=3000)).astype(np.float32)
+    priors = collections.OrderedDict(scale=bvi.tfd.HalfNormal(10.), w=bvi.tfd.Normal(torch.zeros(d), 10.),
+                                     b=bvi.tfd.Normal(0., 10.))
+    model = bvi.Model(priors, lambda scale, w, b, features: bvi.tfd.Normal(loc=bvi.symbolic.matvec(features, w) + b,
+                                                                           scale=scale))
+    df = pd.DataFrame(X, columns=['f%d' % i for i in range(d)]); df['y'] = y3
+    ds = bvi.make_dataset_from_df(df, ['y'], ['f%d' % i for i in range(d)], format_features_as='tensor')
+    post = bvi.MCMC(model, ds).posterior
+    zc = np.concatenate([rng.uniform(0.3, 1.0, (4, 1)), w + 0.05 * rng.normal(size=(4, d)),
+                         0.5 + 0.05 * rng.normal(size=(4, 1))], -1)
+    lp, g = post.unconstrained_log_prob_and_grad(torch.tensor(zc, dtype=torch.float32, device=gpu_device))
+    spec = cf.linreg_model(X, y3)            # oracle layout: (b, w, scale)
+    zo = np.concatenate([zc[:, d + 1:], zc[:, 1:d + 1], zc[:, :1]], -1).astype(np.float32)
+    rlp, rg = spec.log_post_unconstrained(zo)
+    rg_model = np.concatenate([rg[:, d + 1:], rg[:, 1:d + 1], rg[:, :1]], -1)
+    assert_logp_close(lp.cpu().numpy(), rlp); assert_grad_close(g.cpu().numpy(), rg_model)
+    # univariate mixture (univariate-gaussian-mixture-test.ipynb cell 15)
+    k = 3
+    comp = rng.integers(0, k, 500)
+    ym = rng.normal(np.array([-6.0, 0.0, 5.0])[comp], 1.0).astype(np.float32)
+    priors = collections.OrderedDict(weights=bvi.tfd.Dirichlet(torch.ones(k)),
+                                     loc=bvi.tfd.Normal(torch.zeros(k), torch.ones(k) * 10.),
+                                     scale=bvi.tfd.HalfNormal(torch.ones(k) * 10.))
+    model = bvi.Model(priors, lambda weights, loc, scale: bvi.tfd.MixtureSameFamily(
+        mixture_distribution=bvi.tfd.Categorical(probs=weights),
+        components_distribution=bvi.tfd.Normal(loc=loc, scale=scale)))
+    ds = bvi.make_dataset_from_df(pd.DataFrame(dict(y=ym)), ['y'])
+    post = bvi.MCMC(model, ds).posterior
+    z = rng.uniform(-1, 1, (4, 8)) + np.array([0, 0, -6, 0, 5, 0.5, 0.5, 0.5])
+    lp, g = post.unconstrained_log_prob_and_grad(torch.tensor(z, dtype=torch.float32, device=gpu_device))
+    rlp, rg = cf.gmm1d_model(ym, k).log_post_unconstrained(z.astype(np.float32))
+    assert_logp_close(lp.cpu().numpy(), rlp); assert_grad_close(g.cpu().numpy(), rg)
+
+
+def test_config1_nuts_dual_averaging(bvi):
+    """BASELINE configs[0]: univariate Gaussian, 20 points, NUTS + DualAveraging, 2 chains
+    (README.md:146-162; draws reduced to keep the test short).  Moments within Monte-Carlo error of
+    the exact posterior moments (quadrature of the oracle's log posterior)."""
+    rng = np.random.default_rng(1)
+    y = rng.normal(7, 3, 20).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    kernel = bvi.NoUTurnSampler(stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(num_adaptation_steps=400))
+    res = bvi.MCMC(model=model, dataset=ds, transition_kernel=kernel).fit(
+        num_chains=2, num_samples=1500, num_burnin_steps=500, progress_bar=False, seed=5)
+    loc, scale = (s.cpu().numpy() for s in res.samples)
+    assert loc.shape == (1500, 2) and scale.shape == (1500, 2)
+    ml, sl, ms, ss = exact_normal_moments(y.astype(np.float64))
+    # ESS of NUTS here is ~ the number of draws; allow 5 standard errors of 3000 draws + 3 % of sd
+    assert loc.mean() == pytest.approx(ml, abs=5 * sl / math.sqrt(3000) + 0.03 * sl)
+    assert scale.mean() == pytest.approx(ms, abs=5 * ss / math.sqrt(3000) + 0.03 * ss)
+    assert loc.std() == pytest.approx(sl, rel=0.12) and scale.std() == pytest.approx(ss, rel=0.15)
+    assert set(res.trace.keys()) == {'is_accepted', 'target_log_prob', 'log_accept_ratio', 'step_size',
+                                     'leapfrogs_taken', 'has_divergence', 'energy'}
+    assert tuple(res.accept_ratios.shape) == (2,) and float(res.accept_ratios.min()) > 0.5
+    assert int(res.trace['leapfrogs_taken'].max()) <= 31
+
+
+def test_regression_rwm_and_hmc(bvi):
+    """README.md:772-791 (RandomWalkMetropolis on the 1-feature regression) and HMC on the same model."""
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 10, 50).astype(np.float32); yy = (7 + 3 * x + rng.normal(0, 10, 50)).astype(np.float32)
+    priors = collections.OrderedDict(beta_0=bvi.tfd.Normal(0., 10.), beta_1=bvi.tfd.Normal(0., 10.),
+                                     scale=bvi.tfd.HalfNormal(10.))
+
+    def likelihood(beta_0, beta_1, scale, features):
+        return bvi.tfd.Normal(loc=beta_0 + beta_1 * features['x'], scale=scale)
+    model = bvi.Model(priors, likelihood)
+    ds = bvi.make_dataset_from_df(pd.DataFrame(dict(x=x, y=yy)), target_names=['y'], feature_names=['x'])
+    A = np.stack([np.ones(50), x], -1); ols = np.linalg.lstsq(A, yy, rcond=None)[0]
+    init = [torch.full((4,), 5.0), torch.full((4,), 2.0), torch.full((4,), 8.0)]
+    hmc = bvi.HamiltonianMonteCarlo(step_size=0.05, num_leapfrog_steps=10,
+                                    stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(300))
+    res = bvi.MCMC(model, ds, hmc).fit(initial_state=init, num_samples=1500, num_burnin_steps=500,
+                                       progress_bar=False, seed=1)
+    b0, b1, sc = (s.cpu().numpy() for s in res.samples)
+    assert b0.shape == (1500, 4)
+    assert b1.mean() == pytest.approx(ols[1], abs=0.05)
+    assert b0.mean() == pytest.approx(ols[0], abs=0.6)
+    assert set(res.trace.keys()) == {'is_accepted', 'target_log_prob', 'step_size'}
+    rwm = bvi.MCMC(model, ds, bvi.RandomWalkMetropolis()).fit(initial_state=init, num_samples=3000,
+                                                              num_burnin_steps=1000, progress_bar=False, seed=2)
+    assert set(rwm.trace.keys()) == {'is_accepted'}
+    assert rwm.samples[1].cpu().numpy().mean() == pytest.approx(ols[1], abs=0.15)
+
+
+def test_vi_meanfield_advi_and_hnf(bvi):
+    """README.md:264-279 (mean-field ADVI) and :626-637 (Hamiltonian normalizing flow)."""
+    rng = np.random.default_rng(3)
+    y = rng.normal(7, 3, 100).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    ml, sl, ms, ss = exact_normal_moments(y.astype(np.float64))
+    torch.manual_seed(0)
+    vi = bvi.VI(model=model, dataset=ds, surrogate_posterior=bvi.ADVI(model=model, mean_field=True))
+    approx, losses = vi.fit(optimizer=bvi.Adam(learning_rate=5e-2), num_steps=1500, sample_size=10,
+                            num_samples_to_approx_marginals=4000, progress_bar=False)
+    assert losses.shape == (1500,) and losses[-100:].mean() < losses[:50].mean()
+    assert float(approx['loc'].mean()) == pytest.approx(ml, abs=4 * sl)
+    assert float(approx['scale'].mean()) == pytest.approx(ms, abs=4 * ss)
+    assert float(approx['loc'].stddev()) == pytest.approx(sl, rel=0.5)
+    # ELBO <= log evidence: final loss above the negative log marginal likelihood (from quadrature)
+    spec = cf.normal_model(y.astype(np.float64))
+    L, S = np.meshgrid(np.linspace(ml - 8 * sl, ml + 8 * sl, 321), np.linspace(ms * 0.4, ms * 2.5, 401), indexing='ij')
+    lp, _ = spec.log_post_constrained(np.stack([L.ravel(), S.ravel()], -1))
+    log_ev = np.log(np.exp(lp - lp.max()).sum() * (L[1, 0] - L[0, 0]) * (S[0, 1] - S[0, 0])) + lp.max()
+    assert losses[-200:].mean() > -log_ev - 0.05
+    assert losses[-200:].mean() < -log_ev + 1.0
+    # full-rank ADVI and an augmented Hamiltonian flow run and improve the loss
+    vi = bvi.VI(model=model, dataset=ds, surrogate_posterior=bvi.ADVI(model=model, mean_field=False))
+    _, l2 = vi.fit(optimizer=bvi.Adam(learning_rate=5e-2), num_steps=300, sample_size=10,
+                   num_samples_to_approx_marginals=100, progress_bar=False)
+    assert l2[-50:].mean() < l2[:20].mean()
+    nd = model.flat_unconstrained_param_event_ndims
+    flow = bvi.HamiltonianFlow(nd, step_sizes=torch.nn.Parameter(torch.tensor(0.1)), num_integration_steps=2)
+    sp = bvi.NormalizingFlow(model=model, flow_bijector=flow, extra_ndims=nd)
+    vi = bvi.VI(model=model, dataset=ds, surrogate_posterior=sp)
+    _, l3 = vi.fit(optimizer=bvi.Adam(learning_rate=1e-2), num_steps=300, sample_size=10,
+                   num_samples_to_approx_marginals=100, progress_bar=False)
+    assert np.isfinite(l3).all() and l3[-50:].mean() < l3[:20].mean()
