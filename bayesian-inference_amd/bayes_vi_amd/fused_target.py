@@ -24,22 +24,21 @@ from . import _native
 from .bijectors import Blockwise
 
 
-class FusedLogLikelihood:
-    """Base: value and gradient of sum_i log p(y_i | theta_c, x_i) for all chains c.
+class ShardedLogLikelihood:
+    """Value and gradient of sum_i log p(y_i | theta_c, x_i) for all chains c, where this
+    process holds one row shard of the dataset.
 
-    `group`: a torch.distributed process group whose ranks each hold a disjoint
-    row shard of the dataset; the [C, 1+P] partial sums are all-reduced over it
-    (RCCL on GPUs).  `None` = single shard.
+    `group`: a torch.distributed process group whose ranks each hold a disjoint row shard;
+    the [C, 1+P] partial sums (log-likelihood and gradient, one flat buffer) are summed over
+    it with ONE all-reduce per evaluation (RCCL on GPUs, gloo in CPU tests).  Chains are
+    replicated: every rank evaluates the same theta and ends up with the same totals.
+    `None` = single shard.  Subclasses implement `_call` (the local partial sums).
     """
     family = None
     n_params = None
 
     def __init__(self, device, group=None):
         self.device = torch.device(device)
-        if self.device.type != 'cuda':
-            raise _native.BviError('the fused log-likelihood runs on MI355X only; got device %s' % device)
-        _native.lib()
-        self.ws = _native.Workspace(self.device)
         self.group = group
         self.sharded = group is not None and dist.is_initialized() and dist.get_world_size(group) > 1
 
@@ -58,6 +57,17 @@ class FusedLogLikelihood:
         if self.sharded:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return logp, grad
+
+
+class FusedLogLikelihood(ShardedLogLikelihood):
+    """The local partial sums come from one fused HIP pass through the C ABI.  MI355X only."""
+
+    def __init__(self, device, group=None):
+        super().__init__(device, group)
+        if self.device.type != 'cuda':
+            raise _native.BviError('the fused log-likelihood runs on MI355X only; got device %s' % device)
+        _native.lib()
+        self.ws = _native.Workspace(self.device)
 
 
 def _launch(fn, *args):
@@ -85,7 +95,7 @@ class LinearRegression(FusedLogLikelihood):
     """y_i ~ Normal(beta_0 + x_i . w, scale); theta = (beta_0, w[D], scale).  README.md:747-756."""
     family = _native.FAMILY_LINREG
 
-    def __init__(self, X, y, group=None, precision=_native.PREC_AUTO):
+    def __init__(self, X, y, group=None, precision=_native.PREC_AUTO, pack=True):
         super().__init__(X.device, group)
         self.X = X.to(torch.float32).contiguous()
         if self.X.dim() == 1:
@@ -94,10 +104,28 @@ class LinearRegression(FusedLogLikelihood):
         self.n, self.d = self.X.shape
         self.n_params = self.d + 2
         self.precision = precision
+        self.pack = pack
+        self.packed = None        # bf16 piece planes, built once on the first many-chain evaluation
+
+    def _wants_bf16(self, c):
+        if self.d not in (32, 64):
+            return False
+        if self.precision in (_native.PREC_BF16X3, _native.PREC_BF16X6):
+            return True
+        return self.precision == _native.PREC_AUTO and c >= 128 and self.n >= 16384
 
     def _call(self, theta, logp, grad):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d))
+        if self.pack and self._wants_bf16(c):
+            # the dataset is immutable after construction (mcmc.py:52): split it into the bf16
+            # pieces of the matrix-core kernel once, then every evaluation stages tiles by plain copies
+            if self.packed is None:
+                self.packed = _native.linreg_pack(self.X, self.y)
+            _launch(_native.lib().bvi_linreg_packed_logp_grad, _native._ptr(self.packed), self.n, self.d,
+                    _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad),
+                    _native._ptr(buf), buf.numel(), _native._stream())
+            return
         _launch(_native.lib().bvi_linreg_logp_grad, _native._ptr(self.X), _native._ptr(self.y), self.n, self.d,
                 _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), _native._ptr(buf),
                 buf.numel(), _native._stream())
@@ -130,7 +158,7 @@ class Posterior:
     (param_names order, each part row-major flattened: mcmc.py:83-99).
     """
 
-    def __init__(self, likelihood: FusedLogLikelihood, priors, bijectors):
+    def __init__(self, likelihood: ShardedLogLikelihood, priors, bijectors):
         self.likelihood = likelihood
         self.priors = [p for p, _ in priors]
         self.csizes = [int(s) for _, s in priors]

@@ -78,7 +78,7 @@ class VI(Inference):
                 if p.grad is not None:     # tf.clip_by_norm(grad, 1.0), without a host sync
                     p.grad.mul_(torch.clamp(1.0 / (p.grad.norm() + 1e-30), max=1.0))
             opt.step()
-            losses[i] = float(loss)
+            losses[i] = float(loss.detach())
         approx_posterior = self.surrogate_posterior.approx_joint_marginal_posteriors(num_samples_to_approx_marginals)
         return approx_posterior, losses
 

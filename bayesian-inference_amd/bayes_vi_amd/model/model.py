@@ -18,7 +18,8 @@ import torch
 from .. import bijectors as tfb
 from .. import distributions as tfd
 from .. import symbolic as sym
-from ..fused_target import (FusedLogLikelihood, GaussianMixture1D, LinearRegression, NormalIID, Posterior)
+from ..fused_target import (FusedLogLikelihood, GaussianMixture1D, LinearRegression, NormalIID, Posterior,
+                            ShardedLogLikelihood)
 from ..utils import to_ordered_dict
 
 
@@ -26,7 +27,7 @@ def _prod(shape):
     return int(math.prod(shape)) if len(shape) else 1
 
 
-class _MappedLikelihood(FusedLogLikelihood):
+class _MappedLikelihood(ShardedLogLikelihood):
     """Adapts a fused family's parameter layout to the model's flat layout:
     kernel_theta[:, j] = model_theta[:, index[j]] (or the constant 0 where index[j] < 0)."""
 

@@ -1,0 +1,101 @@
+"""world_size-2 gloo test of the row-sharded path: dataset.shard -> local partial sums ->
+one all-reduce of [C, 1+P] -> priors and bijector terms added once.  The local partial sums
+come from the fp64 oracle here (no GPU in this suite); on the GPU box the same
+ShardedLogLikelihood.logp_grad / Posterior code runs over the HIP kernels and RCCL."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bayes_vi_amd import bijectors as tfb
+from bayes_vi_amd import distributions as tfd
+from bayes_vi_amd.fused_target import Posterior, ShardedLogLikelihood
+from bayes_vi_amd.inference.mcmc import samplers
+from bayes_vi_amd.utils.datasets import TensorDataset
+from oracle import closed_form as cf
+
+N, D, C = 1001, 5, 6
+
+
+class OracleLinreg(ShardedLogLikelihood):
+    def __init__(self, X, y, group=None):
+        super().__init__('cpu', group)
+        self.X, self.y = X.numpy(), y.numpy()
+        self.n_params = X.shape[1] + 2
+
+    def _call(self, theta, logp, grad):
+        lp, g = cf.linreg(self.X, self.y, theta.numpy())
+        logp.copy_(torch.tensor(lp, dtype=torch.float32))
+        if grad is not None:
+            grad.copy_(torch.tensor(g, dtype=torch.float32))
+
+
+def make_data():
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(N, D, generator=g); w = torch.randn(D, generator=g)
+    y = 0.3 + X @ w + torch.randn(N, generator=g)
+    z = torch.cat([0.3 + 0.1 * torch.randn(C, 1, generator=g), w + 0.1 * torch.randn(C, D, generator=g),
+                   0.5 + 0.1 * torch.randn(C, 1, generator=g)], -1)
+    return X, y, z
+
+
+def make_posterior(X, y, group):
+    return Posterior(OracleLinreg(X, y, group),
+                     [(tfd.Normal(0., 10.), 1), (tfd.Normal(torch.zeros(D), 10.), D), (tfd.HalfNormal(10.), 1)],
+                     [tfb.Identity(), tfb.Identity(), tfb.Softplus()])
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    X, y, z = make_data()
+    shard = TensorDataset(X, y).shard(rank, world)
+    post = make_posterior(shard.features, shard.targets, dist.group.WORLD)
+    assert post.likelihood.sharded
+    lp, g = post.unconstrained_log_prob_and_grad(z)
+    lpv, _ = post.unconstrained_log_prob_and_grad(z, want_grad=False)
+    # a few HMC steps with the same seed on every rank: chains stay replicated bit for bit
+    k = samplers.HamiltonianMonteCarloKernel(post.unconstrained_log_prob_and_grad, step_size=0.005, num_leapfrog_steps=3)
+    gen = torch.Generator().manual_seed(123)
+    zs, tr = samplers.sample_chain(k, z, 5, 2, generator=gen)
+    gathered = [torch.empty_like(zs) for _ in range(world)]
+    dist.all_gather(gathered, zs)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    if rank == 0:
+        torch.save(dict(lp=lp, g=g, lpv=lpv, zs=zs, rows=shard.cardinality()), out)
+    dist.destroy_process_group()
+
+
+def test_row_sharded_posterior_world2(tmp_path):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    X, y, z = make_data()
+    assert res['rows'] == N // 2
+    post = make_posterior(X, y, None)
+    assert not post.likelihood.sharded
+    lp, g = post.unconstrained_log_prob_and_grad(z)
+    # shard sums are float32 totals of fp64 partials: equal to the unsharded result to f32 rounding
+    np.testing.assert_allclose(res['lp'].numpy(), lp.numpy(), rtol=2e-6)
+    np.testing.assert_allclose(res['g'].numpy(), g.numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(res['lpv'].numpy(), lp.numpy(), rtol=2e-6)
+    # priors are counted once, not once per shard
+    spec = cf.linreg_model(X.numpy(), y.numpy())
+    rlp, rg = spec.log_post_unconstrained(z.numpy())
+    np.testing.assert_allclose(res['lp'].numpy(), rlp, rtol=2e-6)
+    k = samplers.HamiltonianMonteCarloKernel(post.unconstrained_log_prob_and_grad, step_size=0.005, num_leapfrog_steps=3)
+    zs, _ = samplers.sample_chain(k, z, 5, 2, generator=torch.Generator().manual_seed(123))
+    np.testing.assert_allclose(res['zs'].numpy(), zs.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_shard_covers_all_rows_once():
+    ds = TensorDataset({'a': torch.arange(10.)}, torch.arange(10.))
+    for world in (1, 2, 3, 4, 7, 8):
+        rows = torch.cat([ds.shard(r, world).targets for r in range(world)])
+        assert torch.equal(rows, torch.arange(10.))
+        sizes = [ds.shard(r, world).cardinality() for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
