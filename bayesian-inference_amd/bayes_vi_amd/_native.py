@@ -14,6 +14,17 @@ import torch
 FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV = 0, 1, 2, 3
 PREC_AUTO, PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 
+BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED = 0, 1, 2, 3
+PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
+MAX_PARAM_BLOCKS = 16
+
+
+class ParamBlock(ctypes.Structure):
+    """struct bvi_param_block of include/bvi.h."""
+    _fields_ = [('bijector', ctypes.c_int32), ('size', ctypes.c_int32), ('prior', ctypes.c_int32),
+                ('a', ctypes.c_float), ('b', ctypes.c_float)]
+
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'libbvi_hip.so')
 _lib = None
 
@@ -46,6 +57,18 @@ def lib():
         l.bvi_linreg_packed_bytes.argtypes = [i64, i32, ctypes.POINTER(sz)]
         l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, vp, sz, vp]
         l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
+        bp, u64, f32 = ctypes.POINTER(ParamBlock), ctypes.c_uint64, ctypes.c_float
+        l.bvi_constrain.argtypes = [bp, i32, i32, vp, vp, vp]
+        l.bvi_posterior_assemble.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_leapfrog_pre.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp]
+        l.bvi_leapfrog_post.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_hmc_begin.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_hmc_end.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]
+        l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
+        for name in ('bvi_constrain', 'bvi_posterior_assemble', 'bvi_leapfrog_pre', 'bvi_leapfrog_post',
+                     'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_philox_uint32', 'bvi_philox_normal'):
+            getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack',
                      'bvi_linreg_packed_logp_grad'):
@@ -157,3 +180,25 @@ def linreg_packed_logp_grad(packed, n, d, theta, ws: Workspace, want_grad=True, 
     check(lib().bvi_linreg_packed_logp_grad(_ptr(packed), n, d, _ptr(theta), c, precision, _ptr(logp), _ptr(grad),
                                             _ptr(buf), buf.numel(), _stream()), 'bvi_linreg_packed_logp_grad')
     return logp, grad
+
+
+def make_blocks(specs):
+    """specs: list of (bijector, size, prior, a, b) -> ctypes array of bvi_param_block."""
+    if len(specs) > MAX_PARAM_BLOCKS:
+        raise BviError('at most %d parameter blocks on the device path' % MAX_PARAM_BLOCKS)
+    arr = (ParamBlock * len(specs))()
+    for i, (bij, size, prior, a, b) in enumerate(specs):
+        arr[i] = ParamBlock(bij, size, prior, a, b)
+    return arr
+
+
+def philox_uint32(seed, step, stream_id, n_chains, n_blocks, device):
+    out = torch.empty(n_chains, n_blocks, 4, dtype=torch.int32, device=device)
+    check(lib().bvi_philox_uint32(seed, step, stream_id, n_chains, n_blocks, _ptr(out), _stream()), 'bvi_philox_uint32')
+    return out
+
+
+def philox_normal(seed, step, n_chains, n_params, device):
+    out = torch.empty(n_chains, n_params, dtype=torch.float32, device=device)
+    check(lib().bvi_philox_normal(seed, step, n_chains, n_params, _ptr(out), _stream()), 'bvi_philox_normal')
+    return out

@@ -21,6 +21,8 @@ import torch
 import torch.distributed as dist
 
 from . import _native
+from . import bijectors as _bij
+from . import distributions as _dist
 from .bijectors import Blockwise
 
 
@@ -169,6 +171,41 @@ class Posterior:
         if self.n_constrained != likelihood.n_params:
             raise ValueError('priors describe %d parameters, the likelihood takes %d'
                              % (self.n_constrained, likelihood.n_params))
+
+    def device_blocks(self):
+        """The model as an array of bvi_param_block for the device-side assembly / leapfrog entry
+        points, or None when a prior or bijector is outside what they implement (per-element
+        hyper-parameters, user bijectors): the torch path below then does the same job."""
+        if getattr(self, '_blocks', False) is not False:
+            return self._blocks
+        specs = []
+        for prior, bij, size in zip(self.priors, self.bijector.bijectors, self.csizes):
+            kinds = {_bij.Identity: _native.BIJ_IDENTITY, _bij.Softplus: _native.BIJ_SOFTPLUS,
+                     _bij.Exp: _native.BIJ_EXP, _bij.SoftmaxCentered: _native.BIJ_SOFTMAX_CENTERED}
+            if type(bij) not in kinds:
+                specs = None
+                break
+
+            def scalar(t):
+                t = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
+                return float(t[0]) if bool((t == t[0]).all()) else None
+            if isinstance(prior, _dist.Normal):
+                a, b = scalar(prior.loc), scalar(prior.scale)
+                spec = (_native.PRIOR_NORMAL, a, b)
+            elif isinstance(prior, _dist.HalfNormal):
+                spec = (_native.PRIOR_HALFNORMAL, scalar(prior.scale), 0.0)
+            elif isinstance(prior, _dist.Dirichlet):
+                spec = (_native.PRIOR_DIRICHLET, scalar(prior.concentration), 0.0)
+            else:
+                spec = (None, None, None)
+            if spec[0] is None or spec[1] is None or spec[2] is None:
+                specs = None
+                break
+            specs.append((kinds[type(bij)], size, spec[0], spec[1], spec[2]))
+        if specs is not None and len(specs) > _native.MAX_PARAM_BLOCKS:
+            specs = None
+        self._blocks = _native.make_blocks(specs) if specs is not None else None
+        return self._blocks
 
     # ---- constrained space: the closure of mcmc.py:57-62 / vi.py:46-52 ----
     def log_prior(self, theta, want_grad=True):

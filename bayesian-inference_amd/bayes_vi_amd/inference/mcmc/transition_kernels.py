@@ -45,6 +45,13 @@ class HamiltonianMonteCarlo(TransitionKernel):
         self.trace_fn_metrics = ['is_accepted', 'target_log_prob', 'step_size']
 
     def _make(self, target):
+        # a target that is a GPU `Posterior` whose priors/bijectors the device kernels implement
+        # runs the whole transition on the stream; anything else takes the generic torch kernel
+        post = getattr(target, '__self__', None)
+        if post is not None and hasattr(post, 'device_blocks') and post.likelihood.device.type == 'cuda' \
+                and post.device_blocks() is not None:
+            from .device_hmc import DeviceHamiltonianMonteCarloKernel
+            return DeviceHamiltonianMonteCarloKernel(post, self.step_size, self.num_leapfrog_steps)
         return samplers.HamiltonianMonteCarloKernel(target, self.step_size, self.num_leapfrog_steps)
 
 

@@ -62,6 +62,31 @@ extern "C" {
 #define BVI_PREC_BF16X6 3         /* bf16 3-piece split (6 products, f32 grade) for the residual GEMM,
                                      2-piece (3 products) for the gradient GEMM                        */
 
+/* ---- posterior assembly and HMC state updates on the device ---- */
+#define BVI_MAX_PARAM_BLOCKS 16
+
+/* constraining bijector of a parameter block, forward = constrain (bayes_vi/model/model.py:51-55, 112-116) */
+#define BVI_BIJ_IDENTITY 0
+#define BVI_BIJ_SOFTPLUS 1          /* positive parameters (HalfNormal prior)             */
+#define BVI_BIJ_EXP 2
+#define BVI_BIJ_SOFTMAX_CENTERED 3  /* R^{K-1} -> K-simplex (Dirichlet prior)             */
+
+/* prior of a parameter block (README.md:114-117, 747-751; mixture notebook cell 15) */
+#define BVI_PRIOR_NONE 0
+#define BVI_PRIOR_NORMAL 1          /* Normal(loc = a, scale = b) on every element        */
+#define BVI_PRIOR_HALFNORMAL 2      /* HalfNormal(scale = a) on every element             */
+#define BVI_PRIOR_DIRICHLET 3       /* Dirichlet(concentration = a on all `size` entries) */
+
+/* One entry of Model.priors / Model.constraining_bijectors (bayes_vi/model/model.py:106-116),
+ * in param_names order.  `size` is the flat constrained size of the block. */
+typedef struct bvi_param_block {
+  int32_t bijector;
+  int32_t size;
+  int32_t prior;
+  float a;
+  float b;
+} bvi_param_block;
+
 int bvi_version(void);
 
 /* Human-readable text for a status returned by any entry point (host pointer,
@@ -108,6 +133,52 @@ int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, const floa
  * exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15. */
 int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains,
                         float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- device-side posterior assembly: what tfp.mcmc.TransformedTransitionKernel adds around the
+ * target closure (bayes_vi/inference/mcmc/mcmc.py:153-156).  `blocks` is a HOST array.  With
+ * theta = f(z) (block-wise constrain), P = sum of sizes, Pu = unconstrained size:
+ *   lp[c]     = loglik[c] + sum log prior(theta_c) + forward_log_det_jacobian(z_c)
+ *   grad_z[c] = J(z_c)^T (grad_theta[c] + d log prior / d theta) + d fldj / d z
+ * bvi_constrain writes theta[C,P]; bvi_posterior_assemble also recomputes theta, ADDS the prior
+ * score into grad_theta[C,P] in place, and writes lp[C], grad_z[C,Pu] (grad_theta and grad_z may
+ * both be NULL: value only). */
+int bvi_constrain(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* z, float* theta,
+                  void* stream);
+int bvi_posterior_assemble(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* z,
+                           float* theta, const float* loglik, float* grad_theta, float* lp, float* grad_z,
+                           void* stream);
+
+/* ---- leapfrog / HMC on resident device state: the integrator inside tfp.mcmc.HamiltonianMonteCarlo
+ * and NoUTurnSampler (bayes_vi/inference/mcmc/transition_kernels.py:122-128, 238-246) with the
+ * log-posterior as (minus) the potential, split at the point where the dataset pass -- and, on
+ * several GPUs, the all-reduce of its partial sums -- happens:
+ *   pre :  p += eps/2 grad_z;  z += eps p;  theta = f(z)
+ *   (caller: loglik, grad_theta = fused likelihood pass at theta [+ all-reduce])
+ *   post:  lp, grad_z = assemble(z, loglik, grad_theta);  p += eps/2 grad_z
+ * bvi_hmc_begin saves (z, grad_z, lp), draws the momenta p ~ N(0, I) with Philox4x32-10 keyed by
+ * (seed; step, chain, element) unless momenta_in is given, and records the kinetic energy;
+ * bvi_hmc_end accepts with probability min(1, exp(-dH)) (uniform from the same generator unless
+ * log_u_in is given) and restores the saved state of rejected chains; non-finite energies reject. */
+int bvi_leapfrog_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, float* z,
+                     float* p, const float* grad_z, float* theta, void* stream);
+int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                      const float* z, float* p, float* theta, const float* loglik, float* grad_theta, float* lp,
+                      float* grad_z, void* stream);
+int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* z,
+                  const float* grad_z, const float* lp, const float* momenta_in, float* p, float* z0, float* g0,
+                  float* lp0, float* k0, void* stream);
+int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* log_u_in,
+                float* z, float* grad_z, float* lp, const float* p, const float* z0, const float* g0,
+                const float* lp0, const float* k0, unsigned char* is_accepted, float* log_accept_ratio,
+                void* stream);
+
+/* The generator itself, for tests and for callers that want the same streams: raw Philox4x32-10
+ * blocks out[n_chains, n_blocks, 4] for counter (step lo, step hi, chain, block | stream_id << 28)
+ * and key (seed lo, seed hi); and the standard normals out[n_chains, n_params] that bvi_hmc_begin
+ * draws (stream 0, Box-Muller on 24-bit uniforms). */
+int bvi_philox_uint32(uint64_t seed, uint64_t step, int stream_id, int n_chains, int n_blocks, uint32_t* out,
+                      void* stream);
+int bvi_philox_normal(uint64_t seed, uint64_t step, int n_chains, int n_params, float* out, void* stream);
 
 #ifdef __cplusplus
 }

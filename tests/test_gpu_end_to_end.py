@@ -195,3 +195,56 @@ def test_vi_meanfield_advi_and_hnf(bvi):
     _, l3 = vi.fit(optimizer=bvi.Adam(learning_rate=1e-2), num_steps=300, sample_size=10,
                    num_samples_to_approx_marginals=100, progress_bar=False)
     assert np.isfinite(l3).all() and l3[-50:].mean() < l3[:20].mean()
+
+
+def test_device_philox_matches_oracle(gpu_device):
+    from bayes_vi_amd import _native
+    from oracle import philox
+    raw = _native.philox_uint32(0x1234567890ABCDEF, (5 << 32) | 77, 1, 9, 5, gpu_device).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(raw, philox.draw_blocks(0x1234567890ABCDEF, (5 << 32) | 77, 1, 9, 5))
+    z = _native.philox_normal(42, 3, 50, 23, gpu_device).cpu().numpy()
+    np.testing.assert_allclose(z, philox.normals(42, 3, 50, 23), rtol=2e-5, atol=2e-6)
+
+
+def test_device_hmc_matches_oracle_with_injected_and_philox_randomness(bvi, gpu_device):
+    """bvi_hmc_begin / bvi_leapfrog_pre / bvi_leapfrog_post / bvi_hmc_end against the oracle's HMC
+    step, first with injected momenta and uniforms, then with the Philox streams both sides draw."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import DeviceHamiltonianMonteCarloKernel
+    from oracle import leapfrog as lf, philox
+    rng = np.random.default_rng(4)
+    k = 3
+    comp = rng.integers(0, k, 400)
+    ym = rng.normal(np.array([-6.0, 0.0, 5.0])[comp], 1.0).astype(np.float32)
+    priors = collections.OrderedDict(weights=bvi.tfd.Dirichlet(torch.ones(k)),
+                                     loc=bvi.tfd.Normal(torch.zeros(k), torch.ones(k) * 10.),
+                                     scale=bvi.tfd.HalfNormal(torch.ones(k) * 10.))
+    model = bvi.Model(priors, lambda weights, loc, scale: bvi.tfd.MixtureSameFamily(
+        mixture_distribution=bvi.tfd.Categorical(probs=weights),
+        components_distribution=bvi.tfd.Normal(loc=loc, scale=scale)))
+    ds = bvi.make_dataset_from_df(pd.DataFrame(dict(y=ym)), ['y'])
+    post = bvi.MCMC(model, ds).posterior
+    assert post.device_blocks() is not None
+    spec = cf.gmm1d_model(ym, k)
+    c = 7
+    z = (rng.uniform(-.3, .3, (c, 8)) + np.array([0, 0, -6, 0, 5, 0.5, 0.5, 0.5])).astype(np.float32)
+    p = rng.normal(size=(c, 8)).astype(np.float32); lu = np.log(rng.uniform(size=c)).astype(np.float32)
+    kern = DeviceHamiltonianMonteCarloKernel(post, step_size=0.01, num_leapfrog_steps=4, seed=99)
+    zt = torch.tensor(z, device=gpu_device)
+    st = kern.bootstrap(zt)
+    rlp, rg = spec.log_post_unconstrained(z)
+    assert_logp_close(st['target_log_prob'].cpu().numpy(), rlp); assert_grad_close(st['grad'].cpu().numpy(), rg)
+    z1, st1, tr = kern.one_step(zt, st, momenta=torch.tensor(p, device=gpu_device),
+                                log_uniform=torch.tensor(lu, device=gpu_device))
+    q_ref, acc_ref, lr_ref, lp_ref = lf.hmc_step(spec.log_post_unconstrained, z, p, lu, 0.01, 4)
+    np.testing.assert_array_equal(tr['is_accepted'].cpu().numpy(), acc_ref)
+    np.testing.assert_allclose(z1.cpu().numpy(), q_ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(tr['log_accept_ratio'].cpu().numpy(), lr_ref, atol=5e-3)
+    assert_logp_close(st1['target_log_prob'].cpu().numpy(), lp_ref, rtol=2e-5)
+    assert torch.equal(zt, torch.tensor(z, device=gpu_device))       # the caller's state is not modified
+    # Philox path: the oracle draws the same momenta / uniforms from its numpy generator
+    z2, st2, tr2 = kern.one_step(z1, st1)
+    pm = philox.normals(99, 1, c, 8); lu2 = philox.log_uniform(99, 1, c)
+    q_ref2, acc_ref2, lr_ref2, _ = lf.hmc_step(spec.log_post_unconstrained, z1.cpu().numpy(), pm, lu2, 0.01, 4)
+    safe = np.abs(lu2 - lr_ref2) > 1e-2                              # chains not sitting on the accept boundary
+    np.testing.assert_array_equal(tr2['is_accepted'].cpu().numpy()[safe], acc_ref2[safe])
+    np.testing.assert_allclose(z2.cpu().numpy()[safe], q_ref2[safe], rtol=5e-5, atol=5e-5)

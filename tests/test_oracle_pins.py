@@ -250,3 +250,19 @@ def test_sufficient_statistic_posterior_table():
         assert sd_loc == pytest.approx(psd, abs=0.015)
         assert mean_sc == pytest.approx(sm, abs=0.03)
         assert sd_sc == pytest.approx(ssd, abs=0.015)
+
+
+def test_philox_known_answers():
+    """Published Philox4x32-10 known-answer vectors (Random123 kat_vectors)."""
+    from oracle import philox
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(np.array(ctr, np.uint64), np.array(key, np.uint64))
+        assert tuple(int(v) for v in got) == want
+    z = philox.normals(7, 3, 2000, 8)
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    assert not np.array_equal(philox.normals(7, 3, 4, 8), philox.normals(7, 4, 4, 8))
+    np.testing.assert_array_equal(philox.normals(7, 3, 4, 8), philox.normals(7, 3, 4, 8))
