@@ -44,11 +44,11 @@ def make_shard(n_local, d, rank, device):
     return X, y, w_true
 
 
-def cpu_baseline(n_total, d, seconds_budget=20.0):
+def cpu_baseline(n_total, d, seconds_budget=12.0):
     """Restated TFP-equivalent CPU path (oracle/restated_torch.py) on a bounded sample,
     scaled to the full row count.  Reported only; never a gate."""
     from oracle import restated_torch as rt
-    c_s, n_s, chunk = 32, 200_000, 50_000
+    c_s, n_s, chunk = 64, 1_000_000, 50_000
     g = torch.Generator().manual_seed(7)
     X = torch.randn(n_s, d, generator=g); w = torch.randn(d, generator=g)
     y = 0.5 + X @ w + torch.randn(n_s, generator=g)
@@ -57,7 +57,7 @@ def cpu_baseline(n_total, d, seconds_budget=20.0):
     rt.linreg(X, y, theta, chunk=chunk)        # warm-up
     times = []
     t_start = time.perf_counter()
-    while len(times) < 10 and (time.perf_counter() - t_start) < seconds_budget:
+    while len(times) < 1000 and (time.perf_counter() - t_start) < seconds_budget:
         t0 = time.perf_counter()
         rt.linreg(X, y, theta, chunk=chunk)
         times.append(time.perf_counter() - t0)
@@ -68,7 +68,7 @@ def cpu_baseline(n_total, d, seconds_budget=20.0):
         'value': value, 'unit': 'grad-evals/s (chains x steps) at N=%d' % n_total,
         'cores': torch.get_num_threads(), 'kind': 'port',
         'sample': ('restated TFP-equivalent torch-CPU fp32 path (materialised [C,N] ops + autograd), '
-                   '%d chains x %d rows x D=%d in chunks of %d rows, median of %d runs of %.2f s, '
+                   '%d chains x %d rows x D=%d in chunks of %d rows, median of %d runs of %.3f s each (~12 s of CPU work), '
                    'scaled linearly to N=%d rows' % (c_s, n_s, d, chunk, len(times), t, n_total)),
     }
 
@@ -120,43 +120,45 @@ def main():
     theta0 = torch.cat([0.5 + 0.01 * torch.randn(c, 1, generator=g0),
                         w_true.cpu() + 0.01 * torch.randn(c, d, generator=g0),
                         1.0 + 0.01 * torch.randn(c, 1, generator=g0).abs()], -1).to(device)
-    z = post.bijector.inverse(theta0)
-    g3 = torch.Generator(device='cpu'); g3.manual_seed(3)
-    p = torch.randn(c, post.n_unconstrained, generator=g3).to(device)
+    z = post.bijector.inverse(theta0).contiguous()
+    pu, pc = post.n_unconstrained, post.n_constrained
+    blocks = post.device_blocks(); nb = len(blocks)
+    lib, ptr = _native.lib(), _native._ptr
+    p = _native.philox_normal(3, 0, c, pu, device)          # counter-based momenta, identical on every rank
     eps = args.step_size
-
+    theta = torch.empty(c, pc, dtype=torch.float32, device=device)
+    buf = torch.empty(c * (1 + pc), dtype=torch.float32, device=device)
+    logp, grad = buf[:c], buf[c:].view(c, pc)
+    lp = torch.empty(c, dtype=torch.float32, device=device)
+    g = torch.empty(c, pu, dtype=torch.float32, device=device)
     kernel_events = []
 
-    def value_and_grad(zz, timed):
-        # Posterior.unconstrained_log_prob_and_grad, with HIP events bracketing the fused
-        # likelihood pass on the stream it is launched on (torch's current stream)
-        theta = post.bijector.forward(zz)
+    def likelihood_pass(timed):
+        # HIP events bracket the fused dataset pass on the stream it is launched on (torch's current stream)
         if timed:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        buf = torch.empty(c * (1 + lik.n_params), dtype=torch.float32, device=device)
-        logp, grad = buf[:c], buf[c:].view(c, lik.n_params)
-        lik._call(theta.contiguous(), logp, grad)
+        lik._call(theta, logp, grad)
         if timed:
             e1.record(); kernel_events.append((e0, e1))
         if lik.sharded:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        lp_prior, g_prior = post.log_prior(theta)
-        lp = logp + lp_prior + post.bijector.forward_log_det_jacobian(zz)
-        gz = post.bijector.vjp(zz, grad + g_prior) + post.bijector.grad_fldj(zz)
-        return lp, gz
 
-    lp, g = value_and_grad(z, False)
+    st = _native._stream()
+    _native.check(lib.bvi_constrain(blocks, nb, c, ptr(z), ptr(theta), st), 'bvi_constrain')
+    likelihood_pass(False)
+    _native.check(lib.bvi_posterior_assemble(blocks, nb, c, ptr(z), ptr(theta), ptr(logp), ptr(grad), ptr(lp),
+                                             ptr(g), st), 'bvi_posterior_assemble')
 
-    def leapfrog_step(z, p, g, timed):
-        p = p + 0.5 * eps * g
-        z = z + eps * p
-        lp, g = value_and_grad(z, timed)
-        p = p + 0.5 * eps * g
-        return z, p, g, lp
+    def leapfrog_step(timed):
+        st = _native._stream()
+        _native.check(lib.bvi_leapfrog_pre(blocks, nb, c, eps, ptr(z), ptr(p), ptr(g), ptr(theta), st), 'pre')
+        likelihood_pass(timed)
+        _native.check(lib.bvi_leapfrog_post(blocks, nb, c, eps, ptr(z), ptr(p), ptr(theta), ptr(logp), ptr(grad),
+                                            ptr(lp), ptr(g), st), 'post')
 
     for _ in range(args.warmup):
-        z, p, g, lp = leapfrog_step(z, p, g, False)
+        leapfrog_step(False)
 
     def barrier():
         if world > 1:
@@ -166,7 +168,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        z, p, g, lp = leapfrog_step(z, p, g, True)
+        leapfrog_step(True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -181,6 +183,17 @@ def main():
     uses_bf16 = args.precision in ('auto', 'bf16x3', 'bf16x6') and c >= 128 and n_local >= 16384 and d in (32, 64)
     peak = MFMA_BF16_PEAK_TFLOPS if uses_bf16 else MFMA_F32_PEAK_TFLOPS
     achieved = flops / (kern_ms * 1e-3) / 1e12
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, same
+    # command, full 10M-row shard only); null when the run is not that configuration
+    traffic = None
+    try:
+        if uses_bf16 and n_local == 10_000_000 and c == 1024 and d == 64:
+            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as f:
+                for k, v in json.load(f)['kernels'].items():
+                    if 'linreg_bf16x3_kernel<64, 3, true>' in k:
+                        traffic = v.get('hbm_bytes_per_launch_corrected')
+    except (OSError, ValueError, KeyError):
+        traffic = None
     out = {
         'metric': 'leapfrog grad-evals/sec (chains x steps) at N=10M, D=64; % of HBM roofline',
         'value': c * args.steps / elapsed,
@@ -197,8 +210,8 @@ def main():
                    'parallelism': 'rows sharded over %d GPU(s), chains replicated, all-reduce of [C,1+P] per step' % world},
         'roofline': {
             'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-            'traffic': None,
-            'kernel': 'linreg_bf16x3_kernel<64,3>' if uses_bf16 else 'linreg_f32_kernel',
+            'traffic': traffic,
+            'kernel': 'linreg_bf16x3_kernel<64,3,packed>' if uses_bf16 else 'linreg_f32_kernel',
             'kernel_ms': kern_ms, 'algorithmic_flops_per_launch': flops,
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'achieved_GBps': alg_bytes / (kern_ms * 1e-3) / 1e9,
                     'peak_GBps': HBM_PEAK_GBPS, 'frac': alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
