@@ -133,18 +133,20 @@ __global__ __launch_bounds__(256) void linreg_f32_kernel(const float* __restrict
   const int cb = cg * 16 * NC;
 
   float wf[NC][DT][4], b0[NC];
+  // branch-free: lanes of chains past the end read chain 0 and zero the values, so all loads
+  // of the prologue issue back to back
 #pragma unroll
   for (int t = 0; t < NC; ++t) {
     const int chain = cb + 16 * t + li;
-    const bool ok = chain < C;
-    const float* th = theta + (int64_t)(ok ? chain : 0) * (d + 2);
-    b0[t] = ok ? th[0] : 0.f;
+    const float ok = chain < C ? 1.f : 0.f;
+    const float* th = theta + (int64_t)(chain < C ? chain : 0) * (d + 2);
+    b0[t] = ok * th[0];
 #pragma unroll
     for (int m = 0; m < DT; ++m)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int f = 16 * m + 4 * kq + e;
-        wf[t][m][e] = (ok && f < d) ? -th[1 + f] : 0.f;
+        wf[t][m][e] = -ok * (f < d ? 1.f : 0.f) * th[1 + (f < d ? f : 0)];
       }
   }
   f32x4 g[NC][4];
@@ -160,21 +162,56 @@ __global__ __launch_bounds__(256) void linreg_f32_kernel(const float* __restrict
   const int64_t ntiles = (n + 15) / 16;
   const int64_t stride = (int64_t)nrb * 4;
   int64_t t0 = (int64_t)rb * 4 + wave;
+  // X is read from memory ONCE per tile, in the "column" layout (full 256-B rows, coalesced).
+  // With aligned rows (VEC) the "row" layout of GEMM1 comes from a per-wave transpose through
+  // LDS: 16 rows x 16 chunks of 16 B, chunk c of row r stored at c ^ r so that both the writes
+  // (a row per 16 lanes) and the reads (a column of chunks per 16 lanes) are conflict-free.
+  // Otherwise (odd d or unaligned X) the row layout is loaded from memory as well.
+  __shared__ f32x4 tbuf[VEC ? 4 * 2 * 256 : 1];
+  const bool yvec = (((uintptr_t)y) & 15) == 0;
   f32x4 xa[DT], xb[4], yv;
+  // Full tiles of an aligned, 16-feature-multiple X take a branch-free path (plain 16-B loads);
+  // the generic path guards every element.  The test is wave-uniform.
+  const bool fast_cols = VEC && (d == 16 * DT);
   auto load_tile = [&](int64_t tile, f32x4 (&a)[DT], f32x4 (&b)[4], f32x4& yy) {
     const int64_t r0 = tile * 16;
+    if (fast_cols && yvec && r0 + 16 <= n) {
+      const float* base = X + (r0 + 4 * kq) * d + 4 * li;
 #pragma unroll
-    for (int m = 0; m < DT; ++m) a[m] = ld4<VEC>(X, r0 + li, 16 * m + 4 * kq, d, n);
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(base + j * d);
+      yy = *reinterpret_cast<const f32x4*>(y + r0 + 4 * kq);
+      return;
+    }
+    if (!VEC) {
+#pragma unroll
+      for (int m = 0; m < DT; ++m) a[m] = ld4<VEC>(X, r0 + li, 16 * m + 4 * kq, d, n);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = ld4<VEC>(X, r0 + 4 * kq + j, 4 * li, d, n);
 #pragma unroll
     for (int j = 0; j < 4; ++j) yy[j] = (r0 + 4 * kq + j < n) ? y[r0 + 4 * kq + j] : 0.f;
   };
   if (t0 < ntiles) load_tile(t0, xa, xb, yv);
+  int tb = 0;
   for (; t0 < ntiles; t0 += stride) {
     f32x4 xa_n[DT], xb_n[4], yv_n;
     const int64_t tn = t0 + stride;
     if (tn < ntiles) load_tile(tn, xa_n, xb_n, yv_n);
+    if (VEC) {
+      f32x4* tw = tbuf + (wave * 2 + tb) * 256;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * kq + j;
+        tw[r * 16 + (li ^ r)] = xb[j];
+      }
+      // the wave's own LDS writes must land before its lanes read each other's chunks
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int m = 0; m < DT; ++m) xa[m] = tw[li * 16 + ((4 * m + kq) ^ li)];
+      tb ^= 1;
+    }
     const int64_t r0 = t0 * 16;
 #pragma unroll
     for (int t = 0; t < NC; ++t) {
@@ -196,8 +233,10 @@ __global__ __launch_bounds__(256) void linreg_f32_kernel(const float* __restrict
         for (int e = 0; e < 4; ++e) g[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[j], xb[j][e], g[t][e], 0, 0, 0);
     }
     if (tn < ntiles) {
+      if (!VEC) {
 #pragma unroll
-      for (int m = 0; m < DT; ++m) xa[m] = xa_n[m];
+        for (int m = 0; m < DT; ++m) xa[m] = xa_n[m];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) xb[j] = xb_n[j];
       yv = yv_n;
@@ -271,8 +310,8 @@ static int linreg_valu_blocks(int64_t n) { return clampi(bvi_ceil_div(n, 256), 1
 static int linreg_f32_nc(int c) { return c <= 16 ? 1 : (c <= 32 ? 2 : 4); }
 static int linreg_f32_blocks(int64_t n, int c) {
   const int ncg = bvi_ceil_div(c, 16 * linreg_f32_nc(c));
-  // 64 rows per workgroup pass; aim at ~8 workgroups per CU in flight overall
-  return clampi(bvi_ceil_div(n, 64), 1, clampi(2048 / ncg, 1, BVI_MAX_ROW_BLOCKS));
+  // 64 rows per workgroup pass; one resident generation of workgroups (4 per CU x 256 CUs)
+  return clampi(bvi_ceil_div(n, 64), 1, clampi(1024 / ncg, 1, BVI_MAX_ROW_BLOCKS));
 }
 // AUTO takes the bf16-split kernel only where the contraction dominates and the
 // row count is large enough that its ~2^-17 per-product rounding averages out

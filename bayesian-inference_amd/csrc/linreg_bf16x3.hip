@@ -93,10 +93,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int ks = 0; ks < KS; ++ks) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = cvalid ? -th[1 + 16 * ks + 8 * h + j] : 0.f;
+      for (int j = 0; j < 8; ++j) v[j] = (cvalid ? -1.f : 0.f) * th[1 + 16 * ks + 8 * h + j];
       splitn<NP>(v, wp[ks]);
     }
-    float rem = cvalid ? -th[0] : 0.f;
+    float rem = (cvalid ? -1.f : 0.f) * th[0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wext[j] = (__bf16)0.f;
     if (h == 0) {
