@@ -54,6 +54,7 @@ def lib():
         l.bvi_normal_iid_logp_grad.argtypes = [vp, i64, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, sz, vp]
+        l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_linreg_packed_bytes.argtypes = [i64, i32, ctypes.POINTER(sz)]
         l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, vp, sz, vp]
         l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
@@ -70,7 +71,7 @@ def lib():
                      'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_philox_uint32', 'bvi_philox_normal'):
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
-                     'bvi_gmm1d_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack',
+                     'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack',
                      'bvi_linreg_packed_logp_grad'):
             getattr(l, name).restype = i32
         _lib = l
@@ -202,3 +203,15 @@ def philox_normal(seed, step, n_chains, n_params, device):
     out = torch.empty(n_chains, n_params, dtype=torch.float32, device=device)
     check(lib().bvi_philox_normal(seed, step, n_chains, n_params, _ptr(out), _stream()), 'bvi_philox_normal')
     return out
+
+
+def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True):
+    _check_f32_cuda(Y, theta)
+    n, d = Y.shape
+    c = theta.shape[0]
+    assert theta.shape == (c, k + k * d + k * d * d)
+    logp, grad = _outputs(theta, want_grad)
+    buf = ws.get(workspace_bytes(FAMILY_GMM_FULLCOV, n, c, d=d, k=k))
+    check(lib().bvi_gmm_fullcov_logp_grad(_ptr(Y), n, d, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
+                                          buf.numel(), _stream()), 'bvi_gmm_fullcov_logp_grad')
+    return logp, grad

@@ -118,15 +118,21 @@ def fill_triangular_index(d):
 
 class FillScaleTriL(Bijector):
     """Packed vector [D(D+1)/2] -> lower-triangular matrix flattened to [D*D], with
-    softplus(.) + diag_shift on the diagonal (tfb.FillScaleTriL(Softplus(), diag_shift))."""
+    softplus(.) + diag_shift on the diagonal (tfb.FillScaleTriL(Softplus(), diag_shift)).
+    With `batch` = B the flat vector holds B such blocks back to back ([B, D(D+1)/2] ->
+    [B, D, D] flattened): a parameter like scale_tril[K, D, D] of a mixture."""
 
-    def __init__(self, d, diag_shift=1e-5):
-        self.d, self.diag_shift = d, diag_shift
+    def __init__(self, d, diag_shift=1e-5, batch=1):
+        self.d, self.diag_shift, self.batch = d, diag_shift, batch
         full = fill_triangular_index(d)
         rows, cols = torch.tril_indices(d, d)
-        self._src = full[rows, cols]                 # packed index of every lower-tri entry
-        self._dst = rows * d + cols                  # flat position in the D*D output
-        self._isdiag = rows == cols
+        m, dd = d * (d + 1) // 2, d * d
+        src1, dst1, isd1 = full[rows, cols], rows * d + cols, rows == cols
+        off_u = (torch.arange(batch) * m)[:, None]
+        off_c = (torch.arange(batch) * dd)[:, None]
+        self._src = (src1[None] + off_u).reshape(-1)     # packed index of every lower-tri entry
+        self._dst = (dst1[None] + off_c).reshape(-1)     # flat position in the B*D*D output
+        self._isdiag = isd1[None].expand(batch, -1).reshape(-1)
 
     def _to(self, dev):
         return self._src.to(dev), self._dst.to(dev), self._isdiag.to(dev)
@@ -135,15 +141,15 @@ class FillScaleTriL(Bijector):
         src, dst, isd = self._to(x.device)
         v = x[..., src]
         v = torch.where(isd, F.softplus(v) + self.diag_shift, v)
-        out = x.new_zeros(x.shape[:-1] + (self.d * self.d,))
+        out = x.new_zeros(x.shape[:-1] + (self.batch * self.d * self.d,))
         return out.index_copy(-1, dst, v)
 
     def inverse(self, y):
         src, dst, isd = self._to(y.device)
         v = y[..., dst]
-        vd = v - self.diag_shift
-        v = torch.where(isd, vd + torch.log(-torch.expm1(-vd.clamp_min(1e-30))), v)
-        out = y.new_zeros(y.shape[:-1] + (self.d * (self.d + 1) // 2,))
+        vd = (v - self.diag_shift).clamp_min(1e-30)
+        v = torch.where(isd, vd + torch.log(-torch.expm1(-vd)), v)
+        out = y.new_zeros(y.shape[:-1] + (self.batch * self.d * (self.d + 1) // 2,))
         return out.index_copy(-1, src, v)
 
     def forward_log_det_jacobian(self, x):
@@ -161,11 +167,11 @@ class FillScaleTriL(Bijector):
         out = torch.zeros_like(x)
         return out.index_copy(-1, src[isd], torch.sigmoid(-x[..., src[isd]]))
 
-    def forward_event_size(self, n): return self.d * self.d
-    def inverse_event_size(self, n): return self.d * (self.d + 1) // 2
+    def forward_event_size(self, n): return self.batch * self.d * self.d
+    def inverse_event_size(self, n): return self.batch * self.d * (self.d + 1) // 2
 
     def __repr__(self):
-        return 'FillScaleTriL(d=%d, diag_shift=%g)' % (self.d, self.diag_shift)
+        return 'FillScaleTriL(d=%d, diag_shift=%g, batch=%d)' % (self.d, self.diag_shift, self.batch)
 
 
 class Blockwise(Bijector):

@@ -151,6 +151,26 @@ class GaussianMixture1D(FusedLogLikelihood):
                 _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(), _native._stream())
 
 
+class GaussianMixtureFullCov(FusedLogLikelihood):
+    """y_i ~ sum_k w_k N(mu_k, L_k L_k^T); theta = (weights[K], locs[K, D], scale_tril[K, D, D]).
+    exploratory_experiments/multivariate-gaussian-mixture-density-estimation-test.ipynb cell 7."""
+    family = _native.FAMILY_GMM_FULLCOV
+
+    def __init__(self, Y, k, group=None):
+        super().__init__(Y.device, group)
+        self.Y = Y.to(torch.float32).contiguous()
+        self.n, self.d = self.Y.shape
+        self.k = int(k)
+        self.n_params = self.k * (1 + self.d + self.d * self.d)
+
+    def _call(self, theta, logp, grad):
+        c = theta.shape[0]
+        buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d, k=self.k))
+        _launch(_native.lib().bvi_gmm_fullcov_logp_grad, _native._ptr(self.Y), self.n, self.d, self.k,
+                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(),
+                _native._stream())
+
+
 class Posterior:
     """log pi(theta) = log-likelihood (fused) + sum of log-priors, in constrained
     and unconstrained coordinates.

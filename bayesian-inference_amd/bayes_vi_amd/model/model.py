@@ -18,8 +18,8 @@ import torch
 from .. import bijectors as tfb
 from .. import distributions as tfd
 from .. import symbolic as sym
-from ..fused_target import (FusedLogLikelihood, GaussianMixture1D, LinearRegression, NormalIID, Posterior,
-                            ShardedLogLikelihood)
+from ..fused_target import (FusedLogLikelihood, GaussianMixture1D, GaussianMixtureFullCov, LinearRegression,
+                            NormalIID, Posterior, ShardedLogLikelihood)
 from ..utils import to_ordered_dict
 
 
@@ -152,7 +152,7 @@ class Model:
 
     def describe_likelihood(self, features=None):
         """Symbolic recognition only (no data touched, no GPU): returns a dict with
-        'family' in {'normal_iid', 'linreg', 'gmm1d'}, 'index' (kernel parameter j <- model flat
+        'family' in {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov'}, 'index' (kernel parameter j <- model flat
         index, -1 = constant 0) and, for 'linreg', the design-column recipe:
         'columns' = [[(feature_key, coef), ...] per slope parameter] and 'offset' =
         [(feature_key | None, coef), ...] terms to subtract from y."""
@@ -208,7 +208,17 @@ class Model:
                 index = ([off[mix.probs.name] + j for j in range(k)] + [off[comp.loc.name] + j for j in range(k)]
                          + [off[comp.scale.name] + j for j in range(k)])
                 return dict(family='gmm1d', k=k, index=index)
-            raise sym.UnsupportedLikelihood('only mixtures of univariate Normal(loc[K], scale[K]) are fused so far')
+            if isinstance(comp, tfd.MultivariateNormalTriL) and sym.is_plain_param(comp.loc) \
+                    and sym.is_plain_param(comp.scale_tril) and comp.loc.size % k == 0:
+                d = comp.loc.size // k
+                if comp.scale_tril.size != k * d * d:
+                    raise sym.UnsupportedLikelihood('scale_tril must have shape [K, D, D] with D = %d' % d)
+                index = ([off[mix.probs.name] + j for j in range(k)]
+                         + [off[comp.loc.name] + j for j in range(k * d)]
+                         + [off[comp.scale_tril.name] + j for j in range(k * d * d)])
+                return dict(family='gmm_fullcov', k=k, d=d, index=index)
+            raise sym.UnsupportedLikelihood('only mixtures of Normal(loc[K], scale[K]) or of '
+                                            'MultivariateNormalTriL(loc[K, D], scale_tril[K, D, D]) are fused')
         raise sym.UnsupportedLikelihood('likelihood %s is not one of the fused families '
                                         '(Normal, Normal linear regression, MixtureSameFamily of Normal)'
                                         % type(dist).__name__)
@@ -245,6 +255,8 @@ class Model:
             inner = NormalIID(self._to_device(y), group=group)
         elif desc['family'] == 'gmm1d':
             inner = GaussianMixture1D(self._to_device(y), desc['k'], group=group)
+        elif desc['family'] == 'gmm_fullcov':
+            inner = GaussianMixtureFullCov(self._to_device(y.reshape(-1, desc['d'])), desc['k'], group=group)
         else:
             X, y_adj = self.design_matrix(desc, features, y)
             inner = LinearRegression(self._to_device(X), self._to_device(y_adj), group=group,

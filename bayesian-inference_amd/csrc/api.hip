@@ -28,6 +28,10 @@ int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, 
       if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
       *out_bytes = bvi_ws_gmm1d(n_rows, n_chains, k);
       break;
+    case BVI_FAMILY_GMM_FULLCOV:
+      if (k < 1 || k > 16 || d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+      *out_bytes = bvi_ws_gmm_fullcov(n_rows, n_chains, d, k);
+      break;
     default: return BVI_ERR_UNSUPPORTED;
   }
   return BVI_OK;
@@ -80,6 +84,14 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
   if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_gmm1d(n, n_chains, k)) return BVI_ERR_WORKSPACE;
   return bvi_launch_gmm1d(y, n, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+}
+
+int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
+                              float* logp, float* grad, void* ws, size_t ws_bytes, void* stream) {
+  if ((!Y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (k < 1 || k > 16 || d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < bvi_ws_gmm_fullcov(n, n_chains, d, k)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_gmm_fullcov(Y, n, d, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

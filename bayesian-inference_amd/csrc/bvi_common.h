@@ -48,6 +48,10 @@ int bvi_launch_linreg_pack(const float* X, const float* y, int64_t n, int d, voi
 int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* theta, int c, int prec,
                              float* logp, float* grad, float* ws, hipStream_t s);
 
+int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
+                           float* grad, float* ws, hipStream_t s);
+size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k);
+
 #ifdef __HIPCC__
 // Sum over the lanes that share (lane % CP): butterfly over the upper lane bits.
 template <int CP>

@@ -134,6 +134,15 @@ int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, const floa
 int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains,
                         float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
 
+/* Full-covariance Gaussian mixture: Y[n,d] row-major,
+ * theta[C, k + k*d + k*d*d] = (weights_k, locs[k][d], scale_tril[k][d][d] row-major, entries above the
+ * diagonal ignored) -> logp[C], grad[C, same layout] (gradient of scale_tril is lower triangular).
+ * d <= 32, k <= 16; exact f32 on the matrix cores.  Replaces the likelihood node
+ * MixtureSameFamily(Categorical(probs), MultivariateNormalTriL(locs, scale_tril)) of
+ * exploratory_experiments/multivariate-gaussian-mixture-density-estimation-test.ipynb cell 7. */
+int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
+                              float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- device-side posterior assembly: what tfp.mcmc.TransformedTransitionKernel adds around the
  * target closure (bayes_vi/inference/mcmc/mcmc.py:153-156).  `blocks` is a HOST array.  With
  * theta = f(z) (block-wise constrain), P = sum of sizes, Pu = unconstrained size:

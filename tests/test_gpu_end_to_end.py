@@ -248,3 +248,51 @@ def test_device_hmc_matches_oracle_with_injected_and_philox_randomness(bvi, gpu_
     safe = np.abs(lu2 - lr_ref2) > 1e-2                              # chains not sitting on the accept boundary
     np.testing.assert_array_equal(tr2['is_accepted'].cpu().numpy()[safe], acc_ref2[safe])
     np.testing.assert_allclose(z2.cpu().numpy()[safe], q_ref2[safe], rtol=5e-5, atol=5e-5)
+
+
+def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
+    """BASELINE configs[3] in miniature: full-covariance mixture, FillScaleTriL-constrained Cholesky
+    factors, posterior assembly against the oracle and a short NUTS run."""
+    import bayes_vi_amd.bijectors as tfb
+    rng = np.random.default_rng(6)
+    k, d, n, c = 3, 4, 600, 4
+    m = d * (d + 1) // 2
+    true_mu = np.array([[-6.0] * d, [0.0] * d, [6.0] * d])
+    comp = rng.integers(0, k, n)
+    Y = (true_mu[comp] + rng.normal(size=(n, d))).astype(np.float32)
+    priors = collections.OrderedDict(weights=bvi.tfd.Dirichlet(torch.ones(k)),
+                                     locs=bvi.tfd.Normal(torch.zeros(k, d), 10.),
+                                     scale_tril=bvi.tfd.Normal(torch.zeros(k, d, d), 5.))
+    model = bvi.Model(priors, lambda weights, locs, scale_tril: bvi.tfd.MixtureSameFamily(
+        mixture_distribution=bvi.tfd.Categorical(probs=weights),
+        components_distribution=bvi.tfd.MultivariateNormalTriL(loc=locs, scale_tril=scale_tril)),
+        constraining_bijectors=[tfb.SoftmaxCentered(), tfb.Identity(), tfb.FillScaleTriL(d, 1e-3, batch=k)])
+    df = pd.DataFrame(Y, columns=['y%d' % i for i in range(d)])
+    ds = bvi.make_dataset_from_df(df, target_names=list(df.columns))
+    mc = bvi.MCMC(model, ds, bvi.NoUTurnSampler(step_size=0.02, max_tree_depth=4))
+    post = mc.posterior
+    pu = model.flat_unconstrained_param_event_ndims
+    assert pu == (k - 1) + k * d + k * m
+    z = np.concatenate([rng.normal(0, .2, (c, k - 1)), true_mu.reshape(1, -1) + rng.normal(0, .2, (c, k * d)),
+                        rng.normal(0, .2, (c, k * m)) + 0.3], -1).astype(np.float32)
+    lp, g = post.unconstrained_log_prob_and_grad(torch.tensor(z, device=gpu_device))
+    # oracle: same model with one FillScaleTriL block per component; priors on every entry of the
+    # [K, D, D] parameter (the structurally zero upper entries add the same constant on both sides)
+    blocks = [dict(name='w', size=k, prior=('dirichlet', np.ones(k)), bijector=cf.SoftmaxCentered()),
+              dict(name='mu', size=k * d, prior=('normal', 0.0, 10.0), bijector=cf.Identity())]
+    blocks += [dict(name='L%d' % i, size=d * d, prior=('normal', 0.0, 5.0), bijector=cf.FillScaleTriL(d, 1e-3))
+               for i in range(k)]
+
+    def lik(th):
+        w, mu, L = th[:, :k], th[:, k:k + k * d].reshape(-1, k, d), th[:, k + k * d:].reshape(-1, k, d, d)
+        lpv, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+        return lpv, np.concatenate([gw, gmu.reshape(len(th), -1), gL.reshape(len(th), -1)], -1)
+    spec = cf.ModelSpec(blocks, lik)
+    rlp, rg = spec.log_post_unconstrained(z)
+    assert_logp_close(lp.cpu().numpy(), rlp)
+    assert_grad_close(g.cpu().numpy(), rg, term_scale=np.full_like(rg, 3.0 * n))
+    init = [torch.tensor(a) for a in model.split_state(post.bijector.forward(torch.tensor(z)))]
+    res = mc.fit(initial_state=init, num_samples=30, num_burnin_steps=20, progress_bar=False, seed=3)
+    assert [tuple(s.shape) for s in res.samples] == [(30, c, k), (30, c, k, d), (30, c, k, d, d)]
+    assert all(bool(torch.isfinite(s).all()) for s in res.samples)
+    assert float(res.accept_ratios.mean()) > 0.3

@@ -183,3 +183,28 @@ def test_gmm1d(nat, ws, gpu_device, k, c, n):
     ts = np.concatenate([n / th[:, :k], n / th[:, 2 * k:] * np.ones((c, k)), 3 * n / th[:, 2 * k:]], -1) * 0.3
     assert_logp_close(lp.cpu().numpy(), ref_lp)
     assert_grad_close(g.cpu().numpy(), ref_g, term_scale=ts)
+
+
+@pytest.mark.parametrize('d,k,c,n', [(2, 4, 3, 100), (4, 3, 2, 25), (8, 5, 4, 1000), (32, 16, 2, 500), (32, 16, 5, 4099),
+                                     (16, 8, 7, 2000), (5, 1, 2, 64), (3, 2, 1, 17)])
+def test_gmm_fullcov(nat, ws, gpu_device, d, k, c, n):
+    rng = np.random.default_rng(17 * d + k + c + n)
+    true_mu = rng.integers(-20, 21, (k, d)).astype(np.float64)
+    comp = rng.integers(0, k, n)
+    Y = (true_mu[comp] + rng.normal(size=(n, d)) * 1.5).astype(np.float32)
+    w = (rng.dirichlet(np.ones(k) * 5, c) * rng.uniform(0.5, 2.0, (c, 1))).astype(np.float32)
+    mu = (true_mu[None] + rng.normal(0, 0.3, (c, k, d))).astype(np.float32)
+    L = np.tril(rng.normal(size=(c, k, d, d)) * 0.2)
+    for i in range(d):
+        L[..., i, i] = rng.uniform(1.0, 2.0, (c, k))
+    L = L.astype(np.float32)
+    ref_lp, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+    theta = np.concatenate([w, mu.reshape(c, -1), L.reshape(c, -1)], -1)
+    ref_g = np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
+    lp, g = nat.gmm_fullcov_logp_grad(dev(Y, gpu_device), dev(theta, gpu_device), k, ws)
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    # every row contributes O(1) sized terms to each entry
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=np.full_like(ref_g, 3.0 * n))
+    lp2, g2 = nat.gmm_fullcov_logp_grad(dev(Y, gpu_device), dev(theta, gpu_device), k, ws, want_grad=False)
+    assert g2 is None
+    np.testing.assert_array_equal(lp2.cpu().numpy(), lp.cpu().numpy())

@@ -252,3 +252,35 @@ def test_posterior_moments_match_reference_table(kernel_name):
     assert 0.15 < float(acc) <= 1.0
     if kernel_name == 'nuts':
         assert int(tr['leapfrogs_taken'].max()) <= 31 and not bool(tr['has_divergence'].any())
+
+
+def test_recognise_fullcov_mixture_and_batched_tril():
+    k, d = 3, 2
+    m = d * (d + 1) // 2
+    priors = collections.OrderedDict(weights=tfd.Dirichlet(torch.ones(k)),
+                                     locs=tfd.Normal(torch.zeros(k, d), 10.),
+                                     scale_tril=tfd.Normal(torch.zeros(k, d, d), 5.))
+
+    def likelihood(weights, locs, scale_tril):
+        return tfd.MixtureSameFamily(mixture_distribution=tfd.Categorical(probs=weights),
+                                     components_distribution=tfd.MultivariateNormalTriL(loc=locs, scale_tril=scale_tril))
+    bij = [tfb.SoftmaxCentered(), tfb.Identity(), tfb.FillScaleTriL(d, diag_shift=1e-3, batch=k)]
+    model = Model(priors, likelihood, constraining_bijectors=bij)
+    assert model.flat_param_event_ndims == k + k * d + k * d * d
+    assert model.flat_unconstrained_param_event_ndims == (k - 1) + k * d + k * m
+    desc = model.describe_likelihood()
+    assert desc['family'] == 'gmm_fullcov' and desc['k'] == k and desc['d'] == d
+    assert desc['index'] == list(range(k + k * d + k * d * d))
+    # the batched bijector equals the oracle's single-block bijector applied per component
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(4, k * m))
+    o = cf.FillScaleTriL(d, 1e-3)
+    ref = np.concatenate([o.forward(x[:, i * m:(i + 1) * m]) for i in range(k)], -1)
+    b = bij[2]
+    np.testing.assert_allclose(b.forward(torch.tensor(x)).numpy(), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(b.forward_log_det_jacobian(torch.tensor(x)).numpy(),
+                               sum(o.fldj(x[:, i * m:(i + 1) * m]) for i in range(k)), rtol=1e-12)
+    g = rng.normal(size=ref.shape)
+    refv = np.concatenate([o.vjp(x[:, i * m:(i + 1) * m], g[:, i * d * d:(i + 1) * d * d]) for i in range(k)], -1)
+    np.testing.assert_allclose(b.vjp(torch.tensor(x), torch.tensor(g)).numpy(), refv, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(b.inverse(b.forward(torch.tensor(x))).numpy(), x, rtol=1e-6, atol=1e-6)
