@@ -13,6 +13,7 @@ import torch
 
 FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV = 0, 1, 2, 3
 PREC_AUTO, PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
+PACK_BF16X3, PACK_F16 = 0, 1
 
 BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED = 0, 1, 2, 3
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
@@ -55,9 +56,10 @@ def lib():
         l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, sz, vp]
-        l.bvi_linreg_packed_bytes.argtypes = [i64, i32, ctypes.POINTER(sz)]
-        l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, vp, sz, vp]
-        l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
+        l.bvi_linreg_packed_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]
+        l.bvi_linreg_pack_scratch_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
+        l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, i32, vp, sz, vp, sz, vp]
+        l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, i32, vp, vp, vp, sz, vp]
         bp, u64, f32 = ctypes.POINTER(ParamBlock), ctypes.c_uint64, ctypes.c_float
         l.bvi_constrain.argtypes = [bp, i32, i32, vp, vp, vp]
         l.bvi_posterior_assemble.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -71,7 +73,7 @@ def lib():
                      'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_philox_uint32', 'bvi_philox_normal'):
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
-                     'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack',
+                     'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
                      'bvi_linreg_packed_logp_grad'):
             getattr(l, name).restype = i32
         _lib = l
@@ -161,25 +163,30 @@ def gmm1d_logp_grad(y, theta, k, ws: Workspace, want_grad=True):
     return logp, grad
 
 
-def linreg_pack(X, y):
-    """One-time split of (X, y) into the bf16 piece planes of the matrix-core kernel."""
+def linreg_pack(X, y, fmt=PACK_BF16X3):
+    """One-time split of (X, y) into the piece planes of a matrix-core kernel."""
     _check_f32_cuda(X, y)
     n, d = X.shape
     out = ctypes.c_size_t(0)
-    check(lib().bvi_linreg_packed_bytes(n, d, ctypes.byref(out)), 'bvi_linreg_packed_bytes')
+    check(lib().bvi_linreg_packed_bytes(n, d, fmt, ctypes.byref(out)), 'bvi_linreg_packed_bytes')
     packed = torch.empty(max(int(out.value), 16), dtype=torch.uint8, device=X.device)
-    check(lib().bvi_linreg_pack(_ptr(X), _ptr(y), n, d, _ptr(packed), packed.numel(), _stream()), 'bvi_linreg_pack')
+    check(lib().bvi_linreg_pack_scratch_bytes(d, fmt, ctypes.byref(out)), 'bvi_linreg_pack_scratch_bytes')
+    scratch = torch.empty(max(int(out.value), 16), dtype=torch.uint8, device=X.device)
+    check(lib().bvi_linreg_pack(_ptr(X), _ptr(y), n, d, fmt, _ptr(packed), packed.numel(), _ptr(scratch),
+                                scratch.numel(), _stream()), 'bvi_linreg_pack')
     return packed
 
 
-def linreg_packed_logp_grad(packed, n, d, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO):
+def linreg_packed_logp_grad(packed, n, d, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO,
+                            fmt=PACK_BF16X3):
     _check_f32_cuda(theta)
     c = theta.shape[0]
     assert theta.shape == (c, d + 2)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_LINREG, n, c, d=d))
-    check(lib().bvi_linreg_packed_logp_grad(_ptr(packed), n, d, _ptr(theta), c, precision, _ptr(logp), _ptr(grad),
-                                            _ptr(buf), buf.numel(), _stream()), 'bvi_linreg_packed_logp_grad')
+    check(lib().bvi_linreg_packed_logp_grad(_ptr(packed), n, d, fmt, _ptr(theta), c, precision, _ptr(logp),
+                                            _ptr(grad), _ptr(buf), buf.numel(), _stream()),
+          'bvi_linreg_packed_logp_grad')
     return logp, grad
 
 

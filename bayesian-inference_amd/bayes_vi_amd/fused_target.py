@@ -107,25 +107,33 @@ class LinearRegression(FusedLogLikelihood):
         self.n_params = self.d + 2
         self.precision = precision
         self.pack = pack
-        self.packed = None        # bf16 piece planes, built once on the first many-chain evaluation
+        self.packed = None        # piece planes for a matrix-core kernel, built once on first use
+        self.packed_format = None
 
-    def _wants_bf16(self, c):
-        if self.d not in (32, 64):
-            return False
+    def matrix_core_format(self, c):
+        """Packed format the evaluation of `c` chains runs on, or None for the exact-f32 kernels.
+        AUTO: many chains on a large shard -> the f16-piece kernel (gradient error at the level of
+        the f32 kernel's); BF16X3 / BF16X6 select the bf16-piece kernel explicitly."""
+        if self.d not in (32, 64) or not self.pack:
+            return None
         if self.precision in (_native.PREC_BF16X3, _native.PREC_BF16X6):
-            return True
-        return self.precision == _native.PREC_AUTO and c >= 128 and self.n >= 16384
+            return _native.PACK_BF16X3
+        if self.precision == _native.PREC_AUTO and c >= 128 and self.n >= 16384:
+            return _native.PACK_F16
+        return None
 
     def _call(self, theta, logp, grad):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d))
-        if self.pack and self._wants_bf16(c):
-            # the dataset is immutable after construction (mcmc.py:52): split it into the bf16
+        fmt = self.matrix_core_format(c)
+        if fmt is not None:
+            # the dataset is immutable after construction (mcmc.py:52): split it into the 16-bit
             # pieces of the matrix-core kernel once, then every evaluation stages tiles by plain copies
-            if self.packed is None:
-                self.packed = _native.linreg_pack(self.X, self.y)
+            if self.packed is None or self.packed_format != fmt:
+                self.packed = _native.linreg_pack(self.X, self.y, fmt=fmt)
+                self.packed_format = fmt
             _launch(_native.lib().bvi_linreg_packed_logp_grad, _native._ptr(self.packed), self.n, self.d,
-                    _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad),
+                    fmt, _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad),
                     _native._ptr(buf), buf.numel(), _native._stream())
             return
         _launch(_native.lib().bvi_linreg_logp_grad, _native._ptr(self.X), _native._ptr(self.y), self.n, self.d,

@@ -53,29 +53,55 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
   return bvi_launch_linreg(X, y, n, d, theta, n_chains, precision, logp, grad, (float*)ws, (hipStream_t)stream);
 }
 
-int bvi_linreg_packed_bytes(int64_t n, int d, size_t* out_bytes) {
+int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes) {
   if (!out_bytes || n < 0) return BVI_ERR_ARG;
   if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
-  *out_bytes = bvi_linreg_packed_size(n, d);
+  if (format == BVI_PACK_BF16X3) *out_bytes = bvi_linreg_packed_size(n, d);
+  else if (format == BVI_PACK_F16) *out_bytes = bvi_linreg_f16_packed_size(n, d);
+  else return BVI_ERR_ARG;
   return BVI_OK;
 }
 
-int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, void* packed, size_t packed_bytes,
-                    void* stream) {
-  if (((!X || !y) && n > 0) || n < 0) return BVI_ERR_ARG;
+int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes) {
+  if (!out_bytes) return BVI_ERR_ARG;
   if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
-  if ((!packed && n > 0) || packed_bytes < bvi_linreg_packed_size(n, d)) return BVI_ERR_WORKSPACE;
-  return bvi_launch_linreg_pack(X, y, n, d, packed, (hipStream_t)stream);
+  if (format == BVI_PACK_BF16X3) *out_bytes = 0;
+  else if (format == BVI_PACK_F16) *out_bytes = bvi_linreg_f16_pack_scratch(d);
+  else return BVI_ERR_ARG;
+  return BVI_OK;
 }
 
-int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, const float* theta, int n_chains,
-                                int precision, float* logp, float* grad, void* ws, size_t ws_bytes, void* stream) {
+int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, int format, void* packed,
+                    size_t packed_bytes, void* ws, size_t ws_bytes, void* stream) {
+  if (((!X || !y) && n > 0) || n < 0) return BVI_ERR_ARG;
+  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (format == BVI_PACK_BF16X3) {
+    if ((!packed && n > 0) || packed_bytes < bvi_linreg_packed_size(n, d)) return BVI_ERR_WORKSPACE;
+    return bvi_launch_linreg_pack(X, y, n, d, packed, (hipStream_t)stream);
+  }
+  if (format == BVI_PACK_F16) {
+    if (!packed || packed_bytes < bvi_linreg_f16_packed_size(n, d)) return BVI_ERR_WORKSPACE;
+    if (!ws || ws_bytes < bvi_linreg_f16_pack_scratch(d)) return BVI_ERR_WORKSPACE;
+    return bvi_launch_linreg_f16_pack(X, y, n, d, packed, ws, (hipStream_t)stream);
+  }
+  return BVI_ERR_ARG;
+}
+
+int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, int format, const float* theta,
+                                int n_chains, int precision, float* logp, float* grad, void* ws, size_t ws_bytes,
+                                void* stream) {
   if ((!packed && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X6) return BVI_ERR_ARG;
   if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_linreg(n, n_chains, d)) return BVI_ERR_WORKSPACE;
-  return bvi_launch_linreg_packed(packed, n, d, theta, n_chains, precision, logp, grad, (float*)ws,
-                                  (hipStream_t)stream);
+  if (format == BVI_PACK_BF16X3)
+    return bvi_launch_linreg_packed(packed, n, d, theta, n_chains, precision, logp, grad, (float*)ws,
+                                    (hipStream_t)stream);
+  if (format == BVI_PACK_F16) {
+    if (precision != BVI_PREC_AUTO) return BVI_ERR_UNSUPPORTED;
+    return bvi_launch_linreg_f16(packed, n, d, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+  }
+  return BVI_ERR_ARG;
 }
 
 int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains, float* logp,

@@ -52,6 +52,13 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
                            float* grad, float* ws, hipStream_t s);
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k);
 
+size_t bvi_linreg_f16_packed_size(int64_t n, int d);
+size_t bvi_linreg_f16_pack_scratch(int d);
+int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,
+                                 hipStream_t s);
+int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
+                            float* grad, float* ws, hipStream_t s);
+
 #ifdef __HIPCC__
 // Sum over the lanes that share (lane % CP): butterfly over the upper lane bits.
 template <int CP>

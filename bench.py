@@ -180,17 +180,20 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
     flops = 4.0 * c * n_local * d
     alg_bytes = 4.0 * n_local * (d + 1) + 8.0 * c * (d + 2)
-    uses_bf16 = args.precision in ('auto', 'bf16x3', 'bf16x6') and c >= 128 and n_local >= 16384 and d in (32, 64)
-    peak = MFMA_BF16_PEAK_TFLOPS if uses_bf16 else MFMA_F32_PEAK_TFLOPS
+    fmt = lik.matrix_core_format(c)
+    uses_mfma16 = fmt is not None
+    kernel_name = {None: 'linreg_f32_kernel', _native.PACK_F16: 'linreg_f16_kernel<64, 4>',
+                   _native.PACK_BF16X3: 'linreg_bf16x3_kernel<64, %d, true>' % (2 if prec == _native.PREC_BF16X3 else 3)}[fmt]
+    peak = MFMA_BF16_PEAK_TFLOPS if uses_mfma16 else MFMA_F32_PEAK_TFLOPS
     achieved = flops / (kern_ms * 1e-3) / 1e12
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, same
     # command, full 10M-row shard only); null when the run is not that configuration
     traffic = None
     try:
-        if uses_bf16 and n_local == 10_000_000 and c == 1024 and d == 64:
+        if uses_mfma16 and n_local == 10_000_000 and c == 1024 and d == 64:
             with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as f:
                 for k, v in json.load(f)['kernels'].items():
-                    if 'linreg_bf16x3_kernel<64, 3, true>' in k:
+                    if kernel_name in k:
                         traffic = v.get('hbm_bytes_per_launch_corrected')
     except (OSError, ValueError, KeyError):
         traffic = None
@@ -203,7 +206,8 @@ def main():
         'higher_is_better': True,
         'scaling': 'strong',
         'vs_baseline': None,
-        'dtype': 'f32 (bf16 3-piece split MFMA, f32 accumulate)' if uses_bf16 else 'f32',
+        'dtype': {None: 'f32', _native.PACK_F16: 'f32 (f16 2/3-piece split MFMA, f32 accumulate)',
+                  _native.PACK_BF16X3: 'f32 (bf16 3-piece split MFMA, f32 accumulate)'}[fmt],
         'data': 'synthetic',
         'config': {'workload': 'Bayesian linear regression, HMC leapfrog gradient evaluations (BASELINE configs[1])',
                    'rows': n, 'rows_per_gpu': n_local, 'features': d, 'chains': c, 'precision': args.precision,
@@ -211,7 +215,7 @@ def main():
         'roofline': {
             'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
             'traffic': traffic,
-            'kernel': 'linreg_bf16x3_kernel<64,3,packed>' if uses_bf16 else 'linreg_f32_kernel',
+            'kernel': kernel_name,
             'kernel_ms': kern_ms, 'algorithmic_flops_per_launch': flops,
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'achieved_GBps': alg_bytes / (kern_ms * 1e-3) / 1e9,
                     'peak_GBps': HBM_PEAK_GBPS, 'frac': alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},

@@ -113,19 +113,27 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
                          int n_chains, int precision, float* logp, float* grad,
                          void* ws, size_t ws_bytes, void* stream);
 
-/* The same likelihood on a dataset packed once for the bf16-split matrix-core kernel.
+/* The same likelihood on a dataset packed once for the matrix-core kernels.
  * The reference turns the dataset into two immutable full-batch tensors when the
  * driver is constructed (bayes_vi/inference/mcmc/mcmc.py:52, vi/vi.py:40); packing is the
- * MI355X form of that one-time step: X and y are split into bf16 pieces
- * ([3][n_pad][d] planes + a 16-B row extension, n_pad = n rounded up to 64 with zero
- * rows) so that the per-evaluation kernel stages tiles without any arithmetic.
- * d must be 32 or 64; precision F32 is not available on packed data. */
-int bvi_linreg_packed_bytes(int64_t n, int d, size_t* out_bytes);
-int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, void* packed, size_t packed_bytes,
-                    void* stream);
-int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, const float* theta, int n_chains,
-                                int precision, float* logp, float* grad, void* ws, size_t ws_bytes,
-                                void* stream);
+ * MI355X form of that one-time step, so that the per-evaluation kernel stages tiles by plain
+ * copies.  d must be 32 or 64.  Formats:
+ *   BVI_PACK_BF16X3  three bf16 piece planes [3][n_pad][d] + a 16-B row extension; evaluated with
+ *                    precision BF16X6 (default) or BF16X3;
+ *   BVI_PACK_F16     per-column power-of-two scales, data sums and max|y| in a 1024-B header, f16
+ *                    hi/lo planes [2][n_pad][d] of the scaled X (both GEMMs run on the f16 matrix
+ *                    cores with 2-piece operands) + the row extension; precision must be AUTO.
+ * n_pad = n rounded up to 64 with zero rows.  bvi_linreg_pack needs bvi_linreg_pack_scratch_bytes
+ * of workspace (0 for BF16X3). */
+#define BVI_PACK_BF16X3 0
+#define BVI_PACK_F16 1
+int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes);
+int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes);
+int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, int format, void* packed,
+                    size_t packed_bytes, void* ws, size_t ws_bytes, void* stream);
+int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, int format, const float* theta,
+                                int n_chains, int precision, float* logp, float* grad, void* ws,
+                                size_t ws_bytes, void* stream);
 
 /* Univariate Gaussian mixture: y[n], theta[C,3k] = (weights_k, loc_k, scale_k)
  * -> logp[C], grad[C,3k].  Weights are normalised by their sum, as

@@ -123,6 +123,116 @@ def test_linreg_bf16_split(nat, ws, gpu_device, d, c, n):
     np.testing.assert_array_equal(g_a.cpu().numpy(), same_as[1].cpu().numpy())
 
 
+def _f16_eval(nat, ws, gpu_device, X, y, th):
+    Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
+    pk = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+    lp, g = nat.linreg_packed_logp_grad(pk, X.shape[0], X.shape[1], thd, ws, fmt=nat.PACK_F16)
+    return lp.cpu().numpy(), g.cpu().numpy()
+
+
+@pytest.mark.parametrize('d,c,n', [(64, 1, 1), (64, 128, 64), (64, 256, 1000), (64, 300, 4096 + 17), (32, 128, 5000),
+                                   (64, 1024, 20000), (32, 513, 777), (64, 32, 300), (64, 130, 200000),
+                                   (32, 3, 63), (64, 257, 65)])
+def test_linreg_f16_pieces(nat, ws, gpu_device, d, c, n):
+    """The f16-piece kernel (X in 2 pieces, W in 3, residuals in 2; power-of-two range scaling)
+    must meet the same 1e-5 bar as the exact-f32 kernels."""
+    rng = np.random.default_rng(7 * d + c + n)
+    X, y, th = _linreg_case(rng, n, d, c, spread=0.05 if n < 100000 else 0.005)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
+    assert_logp_close(lp, ref_lp)
+    assert_grad_close(g, ref_g, term_scale=_linreg_term_scale(X, y, th))
+
+
+def test_linreg_f16_pieces_near_mode(nat, ws, gpu_device):
+    """Chains packed tightly around the mode: the gradient is a small difference of large sums and an
+    error in W common to all rows would grow like n (the reason for the third piece of W).  The
+    error must stay within a small multiple of the exact-f32 kernel's own."""
+    rng = np.random.default_rng(99)
+    n, d, c = 400000, 64, 128
+    X, y, th = _linreg_case(rng, n, d, c, spread=0.001)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
+    lp32, g32 = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws,
+                                     precision=nat.PREC_F32)
+    scale = np.abs(ref_g).max(-1, keepdims=True)
+    e16 = (np.abs(g - ref_g) / scale).max()
+    e32 = (np.abs(g32.cpu().numpy() - ref_g) / scale).max()
+    assert_logp_close(lp, ref_lp)
+    assert e16 <= max(4.0 * e32, 1e-5), (e16, e32)
+
+
+def test_linreg_f16_pieces_column_ranges(nat, ws, gpu_device):
+    """Columns six decades apart in scale, off-centre, one heavy-tailed, one constant, one all zero;
+    targets in the hundreds: the per-column / per-chain / residual scales must absorb all of it."""
+    rng = np.random.default_rng(123)
+    n, d, c = 30000, 64, 160
+    colscale = 10.0 ** rng.uniform(-3, 3, d)
+    X = rng.normal(size=(n, d)) + rng.normal(size=d) * 2.0
+    X[:, 5] = np.exp(1.5 * rng.normal(size=n))        # max / median ~ 1e3
+    X[:, 6] = 1.0
+    X = X * colscale
+    X[:, 7] = 0.0
+    X = X.astype(np.float32)
+    w = rng.normal(size=d) / colscale
+    y = (300.0 + X.astype(np.float64) @ w + 3.0 * rng.normal(size=n)).astype(np.float32)
+    th = np.concatenate([300.0 + 0.3 * rng.normal(size=(c, 1)), w * (1 + 0.01 * rng.normal(size=(c, d))),
+                         rng.uniform(2.0, 4.0, (c, 1))], -1).astype(np.float32)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
+    assert_logp_close(lp, ref_lp)
+    # gradient entries differ by the column scales: judge every entry against its own term scale
+    ts = _linreg_term_scale(X, y, th)
+    err = np.abs(g - ref_g)
+    assert (err <= 1e-5 * np.abs(ref_g) + 3e-7 * ts + 1e-30).all(), float((err / (np.abs(ref_g) + ts * 3e-2)).max())
+
+
+def test_linreg_f16_pieces_edge_behaviour(nat, ws, gpu_device):
+    rng = np.random.default_rng(3)
+    X, y, th = _linreg_case(rng, 5000, 64, 130)
+    th[3, 10] = np.nan
+    th[64, 0] = np.inf
+    th[100, -1] = -1.0
+    Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
+    pk = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+    lp, g = nat.linreg_packed_logp_grad(pk, 5000, 64, thd, ws, fmt=nat.PACK_F16)
+    lp2, g2 = nat.linreg_packed_logp_grad(pk, 5000, 64, thd, ws, fmt=nat.PACK_F16)
+    assert torch.equal(lp.isnan(), lp2.isnan()) and torch.equal(lp.nan_to_num(), lp2.nan_to_num())
+    assert torch.equal(g.nan_to_num(), g2.nan_to_num())
+    lp = lp.cpu().numpy()
+    bad = np.zeros(130, bool); bad[[3, 64, 100]] = True
+    assert not np.isfinite(lp[bad]).any() and np.isfinite(lp[~bad]).all()
+    assert np.isfinite(g.cpu().numpy()[~bad]).all()
+    ref_lp, ref_g = cf.linreg(X, y, th[~bad])
+    assert_logp_close(lp[~bad], ref_lp)
+    # no chains beyond the valid ones are touched, no rows beyond n are read: n = 0 gives the empty sum
+    pk0 = nat.linreg_pack(Xd[:0], yd[:0], fmt=nat.PACK_F16)
+    lp0, g0 = nat.linreg_packed_logp_grad(pk0, 0, 64, thd[:2], ws, fmt=nat.PACK_F16)
+    assert (lp0 == 0).all() and (g0 == 0).all()
+    with pytest.raises(nat.BviError):     # this format has one arithmetic; an explicit precision is refused
+        nat.linreg_packed_logp_grad(pk, 5000, 64, thd, ws, fmt=nat.PACK_F16, precision=nat.PREC_F32)
+    with pytest.raises(nat.BviError):
+        nat.linreg_pack(Xd[:, :16].contiguous(), yd, fmt=nat.PACK_F16)
+
+
+def test_linear_regression_auto_runs_f16_pieces(nat, ws, gpu_device):
+    """The host mirror packs once and routes many-chain evaluations on a large shard to the
+    f16-piece kernel; few chains stay on the exact-f32 kernel."""
+    from bayes_vi_amd.fused_target import LinearRegression
+    rng = np.random.default_rng(8)
+    X, y, th = _linreg_case(rng, 20000, 64, 256)
+    Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
+    lik = LinearRegression(Xd, yd)
+    assert lik.matrix_core_format(256) == nat.PACK_F16 and lik.matrix_core_format(64) is None
+    lp, g = lik.logp_grad(thd)
+    pk = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+    lp_p, g_p = nat.linreg_packed_logp_grad(pk, 20000, 64, thd, ws, fmt=nat.PACK_F16)
+    assert torch.equal(lp, lp_p) and torch.equal(g, g_p)
+    lp_s, g_s = lik.logp_grad(thd[:64])
+    lp_f, g_f = nat.linreg_logp_grad(Xd, yd, thd[:64], ws, precision=nat.PREC_F32)
+    assert torch.equal(lp_s, lp_f) and torch.equal(g_s, g_f)
+
+
 @pytest.mark.parametrize('d,c,n', [(64, 128, 5000), (32, 256, 20000)])
 def test_linreg_bf16x3_reduced_precision(nat, ws, gpu_device, d, c, n):
     """BF16X3 (2-piece split in both GEMMs) is the documented reduced-precision mode:

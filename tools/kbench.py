@@ -13,6 +13,7 @@ ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--prec', default='bf16x6')
 ap.add_argument('--check', action='store_true')
 ap.add_argument('--packed', action='store_true')
+ap.add_argument('--f16', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda:0'); ws = nat.Workspace(dev)
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -25,7 +26,10 @@ th = torch.cat([0.5 + 0.01 * torch.randn(a.chains, 1, generator=g, device=dev),
                 w + 0.01 * torch.randn(a.chains, a.d, generator=g, device=dev),
                 1 + 0.01 * torch.rand(a.chains, 1, generator=g, device=dev)], -1)
 prec = {'auto': 0, 'f32': 1, 'bf16x3': 2, 'bf16x6': 3}[a.prec]
-if a.packed:
+if a.f16:
+    pk = nat.linreg_pack(X, y, fmt=nat.PACK_F16)
+    run = lambda: nat.linreg_packed_logp_grad(pk, a.rows, a.d, th, ws, precision=0, fmt=nat.PACK_F16)
+elif a.packed:
     pk = nat.linreg_pack(X, y)
     run = lambda: nat.linreg_packed_logp_grad(pk, a.rows, a.d, th, ws, precision=prec)
 else:
@@ -41,7 +45,7 @@ for _ in range(a.reps):
 ts.sort()
 med = ts[len(ts) // 2]
 fl = 4.0 * a.chains * a.rows * a.d
-print('packed=%s ' % a.packed, end='')
+print('packed=%s f16=%s ' % (a.packed, a.f16), end='')
 print('prec=%s rows=%d chains=%d: median %.3f ms  min %.3f  -> %.1f alg TFLOP/s, %.1f K grad-evals/s'
       % (a.prec, a.rows, a.chains, med, ts[0], fl / med / 1e9, a.chains / med), flush=True)
 if a.check:

@@ -17,8 +17,12 @@ for n, c, spread in [(64, 128, 0.05), (1000, 128, 0.05), (20000, 256, 0.05), (20
                          rng.uniform(0.8, 1.5, (c, 1))], -1).astype(np.float32)
     ref_lp, ref_g = cf.linreg(X, y, th[:32])
     Xd, yd, thd = (torch.tensor(a, device=dev) for a in (X, y, th))
-    for name, p in (('f32', nat.PREC_F32), ('x3', nat.PREC_BF16X3), ('x6', nat.PREC_BF16X6)):
-        lp, g = nat.linreg_logp_grad(Xd, yd, thd, ws, precision=p)
+    pkm = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+    for name, p in (('f32', nat.PREC_F32), ('x3', nat.PREC_BF16X3), ('x6', nat.PREC_BF16X6), ('mix', None)):
+        if p is None:
+            lp, g = nat.linreg_packed_logp_grad(pkm, n, d, thd, ws, fmt=nat.PACK_F16)
+        else:
+            lp, g = nat.linreg_logp_grad(Xd, yd, thd, ws, precision=p)
         lp = lp.cpu().numpy()[:32].astype(np.float64); g = g.cpu().numpy()[:32].astype(np.float64)
         e_lp = np.abs(lp - ref_lp) / np.abs(ref_lp)
         e_g = np.abs(g - ref_g).max(-1) / np.abs(ref_g).max(-1)
