@@ -68,7 +68,7 @@ class MCMC(Inference):
             try:
                 from tqdm import tqdm
                 bar = tqdm(total=num_samples + num_burnin_steps, leave=False)
-                progress = lambda i, n: bar.update(1)
+                progress = lambda i, n: bar.update(i - bar.n)
             except Exception:
                 progress = None
         zs, traces = sample_chain(kernel, z0, num_samples, num_burnin_steps, generator=dgen, progress=progress)

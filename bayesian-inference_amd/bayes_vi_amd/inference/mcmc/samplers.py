@@ -237,6 +237,27 @@ def _log_mean_exp(x):
     return torch.logsumexp(x, 0) - math.log(x.shape[0])
 
 
+def _adapting_many_steps(wrapper, z, state, n, generator=None):
+    """`many_steps` of a step-size adaptation wrapper: transitions that still adapt go one by one
+    (the rule needs every transition's acceptance probability on the host), the rest in one call
+    of the inner kernel."""
+    zs_parts, trace_parts = [], []
+    done = 0
+    while done < n and wrapper.step < wrapper.num_adaptation_steps:
+        z, state, tr = wrapper.one_step(z, state, generator=generator)
+        zs_parts.append(z[None])
+        trace_parts.append({k: torch.as_tensor(v)[None] for k, v in tr.items()})
+        done += 1
+    if done < n:
+        zs, z, state, tr = wrapper.inner.many_steps(z, state, n - done, generator=generator)
+        wrapper.step += n - done
+        zs_parts.append(zs)
+        trace_parts.append(tr)
+    keys = trace_parts[0].keys()
+    traces = {k: torch.cat([p[k].to(z.device) for p in trace_parts], 0) for k in keys}
+    return torch.cat(zs_parts, 0), z, state, traces
+
+
 class SimpleStepSizeAdaptation:
     """Multiplicative step-size rule of tfp.mcmc.SimpleStepSizeAdaptation: while adapting,
     step *= (1 + rate) when the chain-averaged acceptance probability exceeds the target,
@@ -249,9 +270,13 @@ class SimpleStepSizeAdaptation:
         self.rate = float(adaptation_rate)
         self.step = 0
         self.trace_names = inner.trace_names
+        self.supports_many_steps = getattr(inner, 'supports_many_steps', False)
 
     def bootstrap(self, z):
         return self.inner.bootstrap(z)
+
+    def many_steps(self, z, state, n, generator=None):
+        return _adapting_many_steps(self, z, state, n, generator)
 
     def one_step(self, z, state, generator=None):
         z, state, trace = self.inner.one_step(z, state, generator=generator)
@@ -284,9 +309,13 @@ class DualAveragingStepSizeAdaptation:
         self.log_averaging_step = 0.0
         self.step = 0
         self.trace_names = inner.trace_names
+        self.supports_many_steps = getattr(inner, 'supports_many_steps', False)
 
     def bootstrap(self, z):
         return self.inner.bootstrap(z)
+
+    def many_steps(self, z, state, n, generator=None):
+        return _adapting_many_steps(self, z, state, n, generator)
 
     def one_step(self, z, state, generator=None):
         z, state, trace = self.inner.one_step(z, state, generator=generator)
@@ -311,9 +340,19 @@ def sample_chain(kernel, z0, num_results, num_burnin_steps, generator=None, prog
     state = kernel.bootstrap(z)
     if not bool(torch.isfinite(state['target_log_prob']).all()):
         raise ValueError('initial state has non-finite log probability: %s' % state['target_log_prob'])
+    total = num_burnin_steps + num_results
+    if getattr(kernel, 'supports_many_steps', False):
+        # kernels that run whole stretches of transitions per launch: burn-in, then the results
+        if num_burnin_steps > 0:
+            _, z, state, _ = kernel.many_steps(z, state, num_burnin_steps, generator=generator)
+            if progress is not None:
+                progress(num_burnin_steps, total)
+        samples, z, state, tr = kernel.many_steps(z, state, num_results, generator=generator)
+        if progress is not None:
+            progress(total, total)
+        return samples, {name: tr[name] for name in kernel.trace_names}
     samples = torch.empty((num_results,) + tuple(z.shape), dtype=z.dtype, device=z.device)
     traces = {}
-    total = num_burnin_steps + num_results
     for i in range(total):
         z, state, tr = kernel.one_step(z, state, generator=generator)
         if i >= num_burnin_steps:

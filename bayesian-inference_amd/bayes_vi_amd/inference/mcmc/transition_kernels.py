@@ -50,7 +50,11 @@ class HamiltonianMonteCarlo(TransitionKernel):
         post = getattr(target, '__self__', None)
         if post is not None and hasattr(post, 'device_blocks') and post.likelihood.device.type == 'cuda' \
                 and post.device_blocks() is not None:
-            from .device_hmc import DeviceHamiltonianMonteCarloKernel
+            from .device_hmc import (DeviceHamiltonianMonteCarloKernel, FusedHamiltonianMonteCarloKernel,
+                                     fused_family)
+            fam = fused_family(post)
+            if fam is not None:     # small dataset: whole transitions in one launch
+                return FusedHamiltonianMonteCarloKernel(post, fam, self.step_size, self.num_leapfrog_steps)
             return DeviceHamiltonianMonteCarloKernel(post, self.step_size, self.num_leapfrog_steps)
         return samplers.HamiltonianMonteCarloKernel(target, self.step_size, self.num_leapfrog_steps)
 

@@ -15,146 +15,9 @@
 // One thread per chain; parameter vectors are tiny ([C, P] with P <= a few hundred)
 // and stay resident in device memory between the launches of a trajectory.
 #include "bvi_common.h"
+#include "posterior_device.h"
 
 namespace {
-
-struct Blocks {
-  int n;
-  bvi_param_block b[BVI_MAX_PARAM_BLOCKS];
-};
-
-__device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
-
-__device__ __forceinline__ int usize_of(const bvi_param_block& b) {
-  return b.bijector == BVI_BIJ_SOFTMAX_CENTERED ? b.size - 1 : b.size;
-}
-
-// theta = f(z) for one chain; returns fldj(z)
-__device__ float constrain(const Blocks& bl, const float* __restrict__ z, float* __restrict__ theta) {
-  float fldj = 0.f;
-  int oz = 0, ot = 0;
-  for (int i = 0; i < bl.n; ++i) {
-    const bvi_param_block b = bl.b[i];
-    if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED) {
-      float m = 0.f;  // the appended logit is 0
-      for (int j = 0; j < b.size - 1; ++j) m = fmaxf(m, z[oz + j]);
-      float s = expf(-m);
-      for (int j = 0; j < b.size - 1; ++j) s += expf(z[oz + j] - m);
-      const float lse = m + logf(s);
-      float sumlog = 0.f;
-      for (int j = 0; j < b.size; ++j) {
-        const float ly = (j < b.size - 1 ? z[oz + j] : 0.f) - lse;
-        theta[ot + j] = expf(ly);
-        sumlog += ly;
-      }
-      fldj += 0.5f * logf((float)b.size) + sumlog;
-    } else {
-      for (int j = 0; j < b.size; ++j) {
-        const float x = z[oz + j];
-        if (b.bijector == BVI_BIJ_SOFTPLUS) {
-          theta[ot + j] = softplusf(x);
-          fldj += -softplusf(-x);
-        } else if (b.bijector == BVI_BIJ_EXP) {
-          theta[ot + j] = expf(x);
-          fldj += x;
-        } else {
-          theta[ot + j] = x;
-        }
-      }
-    }
-    oz += usize_of(b);
-    ot += b.size;
-  }
-  return fldj;
-}
-
-// log prior(theta) for one chain; adds d log prior / d theta into gth (may be null)
-__device__ float log_prior(const Blocks& bl, const float* __restrict__ theta, float* __restrict__ gth) {
-  float lp = 0.f;
-  int ot = 0;
-  for (int i = 0; i < bl.n; ++i) {
-    const bvi_param_block b = bl.b[i];
-    if (b.prior == BVI_PRIOR_NORMAL) {
-      for (int j = 0; j < b.size; ++j) {
-        const float u = (theta[ot + j] - b.a) / b.b;
-        lp += -0.5f * u * u - 0.5f * BVI_LN2PI - logf(b.b);
-        if (gth) gth[ot + j] += -u / b.b;
-      }
-    } else if (b.prior == BVI_PRIOR_HALFNORMAL) {
-      for (int j = 0; j < b.size; ++j) {
-        const float x = theta[ot + j], u = x / b.a;
-        lp += x < 0.f ? -INFINITY : (0.5f * logf(2.f / 3.14159265358979f) - logf(b.a) - 0.5f * u * u);
-        if (gth) gth[ot + j] += -u / b.a;
-      }
-    } else if (b.prior == BVI_PRIOR_DIRICHLET) {
-      lp += lgammaf(b.a * b.size) - b.size * lgammaf(b.a);
-      for (int j = 0; j < b.size; ++j) {
-        lp += (b.a - 1.f) * logf(theta[ot + j]);
-        if (gth) gth[ot + j] += (b.a - 1.f) / theta[ot + j];
-      }
-    }
-    ot += b.size;
-  }
-  return lp;
-}
-
-// g_z = J(z)^T g_theta + d fldj / dz for one chain
-__device__ void chain_rule(const Blocks& bl, const float* __restrict__ z, const float* __restrict__ theta,
-                           const float* __restrict__ gth, float* __restrict__ gz) {
-  int oz = 0, ot = 0;
-  for (int i = 0; i < bl.n; ++i) {
-    const bvi_param_block b = bl.b[i];
-    if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED) {
-      float inner = 0.f;
-      for (int j = 0; j < b.size; ++j) inner += theta[ot + j] * gth[ot + j];
-      for (int j = 0; j < b.size - 1; ++j)
-        gz[oz + j] = theta[ot + j] * (gth[ot + j] - inner) + 1.f - (float)b.size * theta[ot + j];
-    } else {
-      for (int j = 0; j < b.size; ++j) {
-        const float x = z[oz + j];
-        if (b.bijector == BVI_BIJ_SOFTPLUS) gz[oz + j] = gth[ot + j] * sigmoidf(x) + sigmoidf(-x);
-        else if (b.bijector == BVI_BIJ_EXP) gz[oz + j] = gth[ot + j] * expf(x) + 1.f;
-        else gz[oz + j] = gth[ot + j];
-      }
-    }
-    oz += usize_of(b);
-    ot += b.size;
-  }
-}
-
-// ---- Philox4x32-10 (Salmon et al., SC'11) ----
-struct U4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c;
-}
-
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
-// 4 standard normals from one Philox block (two Box-Muller pairs)
-__device__ __forceinline__ void normal4(U4 r, float* out) {
-  const float r0 = sqrtf(-2.f * logf(u01(r.x))), t0 = 6.283185307179586f * u01(r.y);
-  const float r1 = sqrtf(-2.f * logf(u01(r.z))), t1 = 6.283185307179586f * u01(r.w);
-  out[0] = r0 * cosf(t0);
-  out[1] = r0 * sinf(t0);
-  out[2] = r1 * cosf(t1);
-  out[3] = r1 * sinf(t1);
-}
-
-// counter layout: (step lo, step hi, chain, element block | stream << 28)
-__device__ __forceinline__ U4 draw(uint64_t seed, uint64_t step, uint32_t chain, uint32_t blk, uint32_t stream) {
-  return philox4x32_10(U4{(uint32_t)step, (uint32_t)(step >> 32), chain, blk | (stream << 28)}, (uint32_t)seed,
-                       (uint32_t)(seed >> 32));
-}
 
 __global__ void philox_raw_kernel(uint64_t seed, uint64_t step, uint32_t stream, int n_chains, int n_blocks,
                                   uint32_t* __restrict__ out) {
@@ -286,24 +149,6 @@ __global__ void hmc_end_kernel(int C, int Pu, uint64_t seed, uint64_t step, cons
   }
   accepted[c] = acc ? 1 : 0;
   log_ratio_out[c] = lr;
-}
-
-int make_blocks(const bvi_param_block* blocks, int n_blocks, Blocks* out, int* P, int* Pu) {
-  if (!blocks || n_blocks < 1 || n_blocks > BVI_MAX_PARAM_BLOCKS) return BVI_ERR_ARG;
-  out->n = n_blocks;
-  *P = 0;
-  *Pu = 0;
-  for (int i = 0; i < n_blocks; ++i) {
-    const bvi_param_block b = blocks[i];
-    if (b.size < 1 || b.bijector < BVI_BIJ_IDENTITY || b.bijector > BVI_BIJ_SOFTMAX_CENTERED ||
-        b.prior < BVI_PRIOR_NONE || b.prior > BVI_PRIOR_DIRICHLET)
-      return BVI_ERR_ARG;
-    if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED && b.size < 2) return BVI_ERR_ARG;
-    out->b[i] = b;
-    *P += b.size;
-    *Pu += b.bijector == BVI_BIJ_SOFTMAX_CENTERED ? b.size - 1 : b.size;
-  }
-  return BVI_OK;
 }
 
 inline dim3 chain_grid(int C) { return dim3(bvi_ceil_div(C, 64)); }

@@ -189,6 +189,29 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
                 const float* lp0, const float* k0, unsigned char* is_accepted, float* log_accept_ratio,
                 void* stream);
 
+/* Whole HMC transitions in one launch, for datasets small enough that one workgroup per chain can
+ * re-stream them at every leapfrog step (tens to ~10^5 rows): per transition a Philox momentum draw,
+ * n_leapfrog leapfrog steps with the full-data gradient, and the Metropolis step; n_transitions of them
+ * back to back with position, momentum and gradient held in registers.  The same transition, with the
+ * same random numbers, as bvi_hmc_begin -> n_leapfrog x (bvi_leapfrog_pre, <family>_logp_grad,
+ * bvi_leapfrog_post) -> bvi_hmc_end for transition numbers first_step, first_step + 1, ...; replaces
+ * tfp.mcmc.HamiltonianMonteCarlo.one_step iterated by tfp.mcmc.sample_chain
+ * (bayes_vi/inference/mcmc/transition_kernels.py:122-128, mcmc.py:160-171).
+ *   family      BVI_FAMILY_NORMAL_IID (X unused), BVI_FAMILY_LINREG (X[n,d], d <= 16), BVI_FAMILY_GMM1D (k <= 8)
+ *   blocks      the model's parameter blocks; their constrained size must equal the family's parameter count
+ *   step_sizes  per-chain step sizes [C], or NULL to use step_size for all chains
+ *   z, grad_z, lp   [C,Pu], [C,Pu], [C]: state in, state out; with evaluate_initial != 0 lp and grad_z are
+ *               computed from z first (n_transitions may then be 0: a plain evaluation)
+ *   momenta_in [T,C,Pu], log_u_in [T,C]   optional injected randomness (tests), else Philox
+ *   z_out [T,C,Pu], lp_out [T,C], accepted_out [T,C], log_ratio_out [T,C]   optional per-transition outputs
+ * Single GPU only: the rows are not sharded. */
+int bvi_hmc_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
+                  const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                  const float* step_sizes, int n_leapfrog, int n_transitions, uint64_t seed, uint64_t first_step,
+                  int evaluate_initial, float* z, float* grad_z, float* lp, const float* momenta_in,
+                  const float* log_u_in, float* z_out, float* lp_out, unsigned char* accepted_out,
+                  float* log_ratio_out, void* stream);
+
 /* The generator itself, for tests and for callers that want the same streams: raw Philox4x32-10
  * blocks out[n_chains, n_blocks, 4] for counter (step lo, step hi, chain, block | stream_id << 28)
  * and key (seed lo, seed hi); and the standard normals out[n_chains, n_params] that bvi_hmc_begin

@@ -250,6 +250,112 @@ def test_device_hmc_matches_oracle_with_injected_and_philox_randomness(bvi, gpu_
     np.testing.assert_allclose(z2.cpu().numpy()[safe], q_ref2[safe], rtol=5e-5, atol=5e-5)
 
 
+def _fused_cases(bvi, rng):
+    """(name, model, dataset, oracle spec, start point z[C, Pu]) for the three families of the fused HMC kernel."""
+    out = []
+    y = rng.normal(7, 3, 20).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    out.append(('normal', model, ds, cf.normal_model(y), rng.uniform(-.5, .5, (5, 2)) + np.array([6.0, 1.5])))
+    d = 3
+    X = rng.normal(size=(1500, d)).astype(np.float32); w = rng.normal(size=d)
+    yr = (0.5 + X @ w + rng.normal(size=1500)).astype(np.float32)
+    priors = collections.OrderedDict(b=bvi.tfd.Normal(0., 10.), w=bvi.tfd.Normal(torch.zeros(d), 10.),
+                                     scale=bvi.tfd.HalfNormal(10.))
+    model = bvi.Model(priors, lambda b, w, scale, features: bvi.tfd.Normal(loc=b + bvi.symbolic.matvec(features, w),
+                                                                           scale=scale))
+    df = pd.DataFrame(X, columns=['f%d' % i for i in range(d)]); df['y'] = yr
+    ds = bvi.make_dataset_from_df(df, ['y'], ['f%d' % i for i in range(d)], format_features_as='tensor')
+    z0 = np.concatenate([0.5 + 0.05 * rng.normal(size=(6, 1)), w + 0.05 * rng.normal(size=(6, d)),
+                         0.5 + 0.05 * rng.normal(size=(6, 1))], -1)
+    out.append(('linreg', model, ds, cf.linreg_model(X, yr), z0))
+    k = 3
+    comp = rng.integers(0, k, 400)
+    ym = rng.normal(np.array([-6.0, 0.0, 5.0])[comp], 1.0).astype(np.float32)
+    priors = collections.OrderedDict(weights=bvi.tfd.Dirichlet(torch.ones(k)),
+                                     loc=bvi.tfd.Normal(torch.zeros(k), torch.ones(k) * 10.),
+                                     scale=bvi.tfd.HalfNormal(torch.ones(k) * 10.))
+    model = bvi.Model(priors, lambda weights, loc, scale: bvi.tfd.MixtureSameFamily(
+        mixture_distribution=bvi.tfd.Categorical(probs=weights),
+        components_distribution=bvi.tfd.Normal(loc=loc, scale=scale)))
+    ds = bvi.make_dataset_from_df(pd.DataFrame(dict(y=ym)), ['y'])
+    out.append(('gmm1d', model, ds, cf.gmm1d_model(ym, k),
+                rng.uniform(-.3, .3, (7, 8)) + np.array([0, 0, -6, 0, 5, 0.5, 0.5, 0.5])))
+    return out
+
+
+def test_fused_hmc_kernel_matches_oracle_and_unfused_device_path(bvi, gpu_device):
+    """bvi_hmc_fused (whole transitions in one launch): the evaluation at the start point and one
+    transition with injected randomness against the oracle; five Philox-driven transitions in ONE
+    launch against five transitions of the launch-per-step device path with the same seed."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import (DeviceHamiltonianMonteCarloKernel,
+                                                        FusedHamiltonianMonteCarloKernel, fused_family)
+    from oracle import leapfrog as lf
+    rng = np.random.default_rng(21)
+    for name, model, ds, spec, z in _fused_cases(bvi, rng):
+        post = bvi.MCMC(model, ds).posterior
+        fam = fused_family(post)
+        assert fam is not None, name
+        z = z.astype(np.float32)
+        c, pu = z.shape
+        eps, nl = (0.05, 4) if name == 'normal' else (0.004, 4)
+        fused = FusedHamiltonianMonteCarloKernel(post, fam, step_size=eps, num_leapfrog_steps=nl, seed=7)
+        zt = torch.tensor(z, device=gpu_device)
+        st = fused.bootstrap(zt)
+        rlp, rg = spec.log_post_unconstrained(z)
+        assert_logp_close(st['target_log_prob'].cpu().numpy(), rlp)
+        assert_grad_close(st['grad'].cpu().numpy(), rg)
+        p = rng.normal(size=(c, pu)).astype(np.float32); lu = np.log(rng.uniform(size=c)).astype(np.float32)
+        z1, st1, tr = fused.one_step(zt, st, momenta=torch.tensor(p, device=gpu_device),
+                                     log_uniform=torch.tensor(lu, device=gpu_device))
+        q_ref, acc_ref, lr_ref, lp_ref = lf.hmc_step(spec.log_post_unconstrained, z, p, lu, eps, nl)
+        safe = np.abs(lu - lr_ref) > 1e-2
+        np.testing.assert_array_equal(tr['is_accepted'].cpu().numpy()[safe], acc_ref[safe])
+        np.testing.assert_allclose(z1.cpu().numpy()[safe], q_ref[safe], rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(tr['log_accept_ratio'].cpu().numpy(), lr_ref, atol=5e-3)
+        assert_logp_close(st1['target_log_prob'].cpu().numpy()[safe], lp_ref[safe], rtol=2e-5)
+        assert torch.equal(zt, torch.tensor(z, device=gpu_device))
+        # same seed, same transition counters: the fused launch and the per-step launches agree
+        fused = FusedHamiltonianMonteCarloKernel(post, fam, step_size=eps, num_leapfrog_steps=nl, seed=7)
+        step = DeviceHamiltonianMonteCarloKernel(post, step_size=eps, num_leapfrog_steps=nl, seed=7)
+        zs, zf, stf, trf = fused.many_steps(zt, st, 5)
+        zz, ss = zt, step.bootstrap(zt)
+        ok = np.ones(c, bool)
+        for t in range(5):
+            zz, ss, trs = step.one_step(zz, ss)
+            # a chain whose accept decision sits on the boundary may legitimately differ from here on
+            ok &= np.abs(trs['log_accept_ratio'].cpu().numpy()
+                         - trf['log_accept_ratio'][t].cpu().numpy()) < 1e-3
+            ok &= trs['is_accepted'].cpu().numpy() == trf['is_accepted'][t].cpu().numpy()
+            np.testing.assert_allclose(zs[t].cpu().numpy()[ok], zz.cpu().numpy()[ok], rtol=1e-4, atol=1e-4)
+        assert ok.sum() >= c - 1, name
+        assert torch.equal(zs[-1], zf)
+        assert_logp_close(stf['target_log_prob'].cpu().numpy()[ok], ss['target_log_prob'].cpu().numpy()[ok], rtol=5e-5)
+
+
+def test_fused_hmc_through_mcmc_fit_posterior_moments(bvi):
+    """BASELINE configs[0] data (20 points) through MCMC.fit with HMC: the driver picks the fused
+    kernel, adapts the step size transition by transition, then draws every sample in one launch.
+    Posterior moments within Monte-Carlo error of the exact ones."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import FusedHamiltonianMonteCarloKernel
+    rng = np.random.default_rng(1)
+    y = rng.normal(7, 3, 20).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    hmc = bvi.HamiltonianMonteCarlo(step_size=0.1, num_leapfrog_steps=8,
+                                    stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(300))
+    mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=hmc)
+    kernel, _ = hmc(mcmc.posterior.unconstrained_log_prob_and_grad)
+    assert isinstance(kernel.inner, FusedHamiltonianMonteCarloKernel)
+    res = mcmc.fit(num_chains=8, num_samples=4000, num_burnin_steps=500, progress_bar=False, seed=3)
+    loc, scale = (s.cpu().numpy() for s in res.samples)
+    assert loc.shape == (4000, 8) and res.trace['is_accepted'].shape == (4000, 8)
+    assert 0.5 < float(res.trace['is_accepted'].float().mean()) < 0.98
+    ml, sl, ms, ss = exact_normal_moments(y.astype(np.float64))
+    n_eff = 4000 * 8 / 4.0      # HMC with 8 leapfrog steps decorrelates within a few transitions
+    assert loc.mean() == pytest.approx(ml, abs=5 * sl / math.sqrt(n_eff) + 0.02 * sl)
+    assert scale.mean() == pytest.approx(ms, abs=5 * ss / math.sqrt(n_eff) + 0.02 * ss)
+    assert loc.std() == pytest.approx(sl, rel=0.08) and scale.std() == pytest.approx(ss, rel=0.10)
+
+
 def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
     """BASELINE configs[3] in miniature: full-covariance mixture, FillScaleTriL-constrained Cholesky
     factors, posterior assembly against the oracle and a short NUTS run."""
@@ -291,7 +397,7 @@ def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
     rlp, rg = spec.log_post_unconstrained(z)
     assert_logp_close(lp.cpu().numpy(), rlp)
     assert_grad_close(g.cpu().numpy(), rg, term_scale=np.full_like(rg, 3.0 * n))
-    init = [torch.tensor(a) for a in model.split_state(post.bijector.forward(torch.tensor(z)))]
+    init = [a.clone() for a in model.split_state(post.bijector.forward(torch.tensor(z)))]
     res = mc.fit(initial_state=init, num_samples=30, num_burnin_steps=20, progress_bar=False, seed=3)
     assert [tuple(s.shape) for s in res.samples] == [(30, c, k), (30, c, k, d), (30, c, k, d, d)]
     assert all(bool(torch.isfinite(s).all()) for s in res.samples)
