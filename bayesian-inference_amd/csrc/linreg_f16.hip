@@ -5,8 +5,8 @@
 // piece of W matters although it is 2^-22 of W: an error in W is the same for every row, so it
 // acts like evaluating the gradient at a shifted parameter and grows with n, not sqrt(n).
 // Gradient GEMM, 3 products: R = rh + rl times X: rh.xh, rl.xh, rh.xl.
-// 29 MFMAs per 32 rows x 32 chains at D = 64 where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3
-// products) needs 37, on half the bytes (two 2-byte planes of X = the size of the f32 matrix).
+// 7 f16 products where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3 products) needs 9, on two
+// 2-byte planes of X (= the size of the f32 matrix) instead of three.
 // Same likelihood node as there: tfd.Normal(beta_0 + X w, scale)
 // (bayes_vi/model/model.py:194-203, README.md:754-756).
 //
@@ -17,29 +17,44 @@
 //   w''_cd = -w_cd / s_d * t_c,  t_c = 2^(13 - floor(log2 max_d |w_cd / s_d|))  (per chain, per call)
 // so that |x'|, |w''| < 2^14 and z' = sum_d x'_id w''_cd = -t_c x_i.w_c accumulates in f32; the low
 // pieces then sit 2^-11 below, far above the f16 subnormal threshold for every element that
-// matters to the sum.  r = (y - b0) + z' / t_c, with y - b0 from one bf16 k-step over the row
-// extension (as in linreg_bf16x3.hip).  The residuals enter the gradient GEMM as
-//   r'_ic = r_ic * u_c,    u_c = 2^(14 - floor(log2 (max|y| + |b0| + D 2^14 max_d |w_cd / s_d|)))
+// matters to the sum.  The residuals are produced already scaled for the gradient GEMM,
+//   r'_ic = u r_ic = z'_ic (u / t_c) + (u y_i - u b0_c),
+//   u = min over the workgroup's chains of 2^(14 - floor(log2 (max|y| + |b0_c| + D 2^14 max_d |w_cd / s_d|)))
 // : the bound holds for every row, so |r'| < 2^15, and it is loose by a few binades only, which
-// leaves ~20 binades of f16 range below a typical residual.  G'_cd = sum_i r'_ic x'_id is rescaled
-// by 1 / (u_c s_d) in the finalize kernel (exact: powers of two).
-// S1 = sum_i r_i is not accumulated at all: it equals sum y - n b0 - w . (column sums of X), with
-// the data sums taken once, in double, at pack time.
+// leaves ~20 binades of f16 range below a typical residual.  u is one number per workgroup so that
+// u y_i is formed once, when a tile is staged, and not per chain.  S2' = sum r'^2 and
+// G'_cd = sum_i r'_ic x'_id are rescaled by 1 / u^2 and 1 / (u s_d) in the finalize kernel (exact:
+// powers of two).  S1 = sum_i r_i is not accumulated at all: it equals sum y - n b0 - w . (column
+// sums of X), with the data sums taken once, in double, at pack time.
 //
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
 //   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
-//   planes [2][n_pad][D] f16: hi(x'), lo(x')
-//   ext    [n_pad][8] bf16: [y0 y1 y2 1 1 1 0 0]   (all zero for padding rows)
+//   planes [2][n_pad][D] f16: hi(x'), lo(x')           (all zero for padding rows)
+//   y      [n_pad] f32                                 (0 for padding rows)
+//
+// Matrix instruction: v_mfma_f32_16x16x32_f16 (wave64).  A[m][k]: lane l holds m = l & 15,
+// k = 8 (l >> 4) .. + 7; B[k][n]: lane l holds n = l & 15, same k; D[m][n]: lane l, register i holds
+// m = 4 (l >> 4) + i, n = l & 15.  GEMM1: M = rows (A = X from LDS), N = chains (B = -W'' resident in
+// registers), so a lane's accumulator registers are rows 4g + i of its chain (g = l >> 4).  Two such
+// row tiles side by side are, lane for lane, the A operand of GEMM2 (M = chains, K = rows,
+// N = features) with k index j <-> row 16 (j >> 2) + 4 g + (j & 3) of the 32-row pair; the B operand
+// takes the same row order from two transposed LDS reads (ds_read_b64_tr_b16).
+//
+// The loop is bound by vector-instruction issue (an MFMA of this shape holds the issue port for 8
+// of its 16 cycles), so everything per residual that is not an MFMA is kept to: two fma (assemble
+// r'), one fma (S2'), one packed convert and one mixed-precision fma (hi / lo split).
 #include "bvi_common.h"
 
 namespace {
 
-constexpr int kThreads = 512;
-constexpr int kChainsPerBlock = 256;
-constexpr int kTileRows = 64;
+constexpr int kTileRows = 128;             // rows staged per barrier; processed as 64-row halves
 constexpr int kHeader = 1024;
+constexpr int kWaves = 8;                 // waves per workgroup; the workgroup owns 32 * kWaves chains
+constexpr int kMaxRowBlocks = 256;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct Header {
@@ -69,158 +84,140 @@ __device__ __forceinline__ float pow2_scale(float amax) {
   return ldexpf(1.f, min(max(13 - ilogbf(amax), -126), 126));
 }
 
-template <int D, int NP1>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_kernel(
+// (q0, q1) -> packed f16 (hi0, hi1) and (lo0, lo1) with lo = f16(q - hi): one packed convert and two
+// mixed-precision fma that read the f16 halves directly
+__device__ __forceinline__ void split_pair(float q0, float q1, unsigned& hi, unsigned& lo) {
+  asm volatile(
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(q0), "v"(q1));
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_kernel(
     const unsigned char* __restrict__ packed, int64_t n, const float* __restrict__ theta, int C, int ncb, int nrb,
-    float* __restrict__ partials) {
-  constexpr int KS = D / 16;
-  constexpr int NT = D / 32;
-  constexpr int SA = 2 * D + 16;
+    float* __restrict__ partials, float* __restrict__ ublk) {
+  constexpr int KS = D / 32;   // k-steps of GEMM1
+  constexpr int FT = D / 16;   // feature tiles of GEMM2
+  constexpr int SA = 2 * D;    // LDS row stride: no padding, 16-B chunks XOR-swizzled by row (swz below)
   constexpr int IMG = kTileRows * SA;
-  constexpr int EXT = kTileRows * 16;
-  constexpr int BUF = 2 * IMG + EXT;
+  constexpr int BUF = 2 * IMG + 2 * kTileRows * 4;   // two planes, u*y, u*valid
   constexpr int TPR = D / 8;
+  constexpr int NT = 64 * NW;
+  constexpr int NCH = kTileRows * TPR;               // 16-B chunks of one plane of a tile
+  constexpr int PER = (NCH + NT - 1) / NT;           // chunks staged per thread and plane
+  constexpr int YT = NT / kTileRows;                 // threads staging the same y
+  static_assert(NT % kTileRows == 0, "y staging needs a whole number of threads per row");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ float sh_u[NW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
+  const int ln = lane & 15, g = lane >> 4;
   const int x8 = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
-  const int chain = cbi * kChainsPerBlock + 32 * wave + r;
-  const bool cvalid = chain < C;
+  const int cbase = cbi * (32 * NW) + 32 * wave;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
   const int64_t n_pad = ntiles * kTileRows;
   const unsigned char* planes = packed + kHeader;
-  const unsigned char* ext = planes + (int64_t)2 * n_pad * D * 2;
+  const unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
 
-  // scaled -W fragments in f16 pieces, the chain's 1/t and residual scale u, and the bf16 extension
-  // fragment for y - b0
-  f16x8 wh[KS], wl[KS], w3[KS];
-  bf16x8 wext;
-  float inv_t, u;
+  // scaled -W fragments in three f16 pieces; per chain: c1 = u / t and nb0 = -b0
+  f16x8 w1[2][KS], w2[2][KS], w3[2][KS];
+  float nb0[2], c1[2];
+  float u;
   {
-    const float* th = theta + (int64_t)(cvalid ? chain : 0) * (D + 2);
-    float v[KS][8], amax = 0.f;
+    float umin = INFINITY;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ct = 0; ct < 2; ++ct) {
+      const int chain = cbase + 16 * ct + ln;
+      const bool cvalid = chain < C;
+      const float* th = theta + (int64_t)(cvalid ? chain : 0) * (D + 2);
+      float v[KS][8], amax = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int f = 16 * ks + 8 * h + j;
-        v[ks][j] = (cvalid ? -1.f : 0.f) * scaled_weight(th[1 + f], hdr->colscale[f]);
-        amax = fmaxf(amax, fabsf(v[ks][j]));
-      }
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));     // the two lane halves hold the chain's 64 features
-    const float t = pow2_scale(amax);
-    inv_t = 1.f / t;
-    u = resid_scale(amax, cvalid ? th[0] : 0.f, hdr->ymax, D);
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+        for (int j = 0; j < 8; ++j) {
+          const int f = 32 * ks + 8 * g + j;
+          v[ks][j] = (cvalid ? -1.f : 0.f) * scaled_weight(th[1 + f], hdr->colscale[f]);
+          amax = fmaxf(amax, fabsf(v[ks][j]));
+        }
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));   // the four lane groups hold the chain's D features
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const float t = pow2_scale(amax);
+      c1[ct] = 1.f / t;
+      nb0[ct] = cvalid ? -th[0] : 0.f;
+      umin = fminf(umin, resid_scale(amax, cvalid ? th[0] : 0.f, hdr->ymax, D));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float q = v[ks][j] * t;
-        const _Float16 hi = (_Float16)q;
-        wh[ks][j] = hi;
-        const _Float16 lo = (_Float16)(q - (float)hi);
-        wl[ks][j] = lo;
-        w3[ks][j] = (_Float16)((q - (float)hi) - (float)lo);
-      }
-    float rem = (cvalid ? -1.f : 0.f) * th[0];
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wext[j] = (__bf16)0.f;
-    if (h == 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        wext[j] = (__bf16)1.f;
-        const __bf16 p = (__bf16)rem;
-        wext[3 + j] = p;
-        rem -= (float)p;
-      }
+        for (int j = 0; j < 8; ++j) {
+          const float q = v[ks][j] * t;
+          const _Float16 hi = (_Float16)q;
+          const _Float16 lo = (_Float16)(q - (float)hi);
+          w1[ct][ks][j] = hi;
+          w2[ct][ks][j] = lo;
+          w3[ct][ks][j] = (_Float16)((q - (float)hi) - (float)lo);
+        }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
+    if (lane == 0) sh_u[wave] = umin;
+    __syncthreads();
+    u = sh_u[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) u = fminf(u, sh_u[w]);
+    c1[0] *= u;
+    c1[1] *= u;
+    if (rbi == 0 && tid == 0) ublk[cbi] = u;
   }
 
-  f32x16 G[NT];
+  f32x4v G[2][FT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) G[nt][i] = 0.f;
-  float s2 = 0.f;
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G[ct][ft][i] = 0.f;
+  float s2[2] = {0.f, 0.f};
 
-  const int srow = tid / TPR, scol = (tid % TPR) * 8;
-  const bool sact = (kThreads / TPR == kTileRows) ? true : (srow < kTileRows);
-
-  s16x8 xp[2], ye;
+  // chunk q of row r lives at chunk q ^ swz(r): with it the A-operand ds_read_b128 (lane groups
+  // {0-3,12-15,20-27}, ...: 16 rows, two neighbouring chunks), the transposed ds_read_b64_tr_b16 (32 lanes:
+  // 8 rows x 32 B) and the 128-bit row stores all spread over the 64 banks without conflicts
+  auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
+  s16x8 xp[2][PER];
+  float yp, mp;
   auto gload = [&](int64_t tile) {
-    const int64_t row = (tile < ntiles ? tile : 0) * kTileRows + (sact ? srow : 0);
+    const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      xp[i] = *reinterpret_cast<const s16x8*>(planes + (((int64_t)i * n_pad + row) * D + scol) * 2);
-    ye = *reinterpret_cast<const s16x8*>(ext + row * 16);
+    for (int e = 0; e < PER; ++e) {
+      const int idx = tid + e * NT;
+      const int srow = (NCH % NT == 0 || idx < NCH) ? idx / TPR : 0, ch = idx % TPR;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        xp[i][e] = *reinterpret_cast<const s16x8*>(planes + (((int64_t)i * n_pad + row0 + srow) * D + ch * 8) * 2);
+    }
+    // every thread stages a y (NW threads per row, same value): an unconditional use keeps the
+    // compiler from sinking this load down to the store, where its latency would be exposed
+    yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
+    mp = row0 + tid / YT < n ? u : 0.f;     // padding rows: x = 0, y = 0, and no -b0 either -> r' = 0
   };
   auto lstore = [&](int buf) {
     unsigned char* base = lds + buf * BUF;
-    if (sact) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<s16x8*>(base + i * IMG + srow * SA + scol * 2) = xp[i];
-      *reinterpret_cast<s16x8*>(base + 2 * IMG + srow * 16) = ye;
-    }
-  };
-  // residuals of one 32-row sub-tile: r = (y - b0) + z' / t
-  auto gemm1 = [&](const unsigned char* base, int st) -> f32x16 {
-    f32x16 z, yb;
+    for (int e = 0; e < PER; ++e) {
+      const int idx = tid + e * NT;
+      const int srow = idx / TPR, ch = idx % TPR;
+      if (NCH % NT == 0 || idx < NCH) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { z[i] = 0.f; yb[i] = 0.f; }
-    const bf16x8 ae = *reinterpret_cast<const bf16x8*>(base + 2 * IMG + (32 * st + r) * 16);
-    yb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ae, wext, yb, 0, 0, 0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int off = (32 * st + r) * SA + (16 * ks + 8 * h) * 2;
-      const f16x8 ah = *reinterpret_cast<const f16x8*>(base + off);
-      const f16x8 al = *reinterpret_cast<const f16x8*>(base + IMG + off);
-      z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[ks], z, 0, 0, 0);
-      z = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ks], z, 0, 0, 0);
-      z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ks], z, 0, 0, 0);
-      if (NP1 == 4) z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w3[ks], z, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = fmaf(z[i], inv_t, yb[i]);
-    return z;
-  };
-  auto post = [&](const f32x16& z, f16x8 (&rh)[2], f16x8 (&rl)[2]) {
-    float a2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a2 = fmaf(z[i], z[i], a2);
-    s2 += a2;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float q = z[8 * s + j] * u;
-        const _Float16 hi = (_Float16)q;
-        rh[s][j] = hi;
-        rl[s][j] = (_Float16)(q - (float)hi);
-      }
-  };
-  auto gemm2 = [&](const unsigned char* base, int st, const f16x8 (&rh)[2], const f16x8 (&rl)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int row0 = 32 * st + 16 * s + 4 * h + ((lane & 15) >> 2);
-        const int col = 32 * nt + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-        const int off0 = row0 * SA + col * 2;
-        const int off1 = off0 + 8 * SA;
-        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
-        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
-        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + IMG + off0));
-        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + IMG + off1));
-        const f16x8 xh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-        const f16x8 xl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-        G[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[s], xh, G[nt], 0, 0, 0);
-        G[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[s], xh, G[nt], 0, 0, 0);
-        G[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[s], xl, G[nt], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<s16x8*>(base + i * IMG + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[i][e];
       }
     }
+    *reinterpret_cast<float*>(base + 2 * IMG + (tid / YT) * 4) = yp * u;
+    *reinterpret_cast<float*>(base + 2 * IMG + kTileRows * 4 + (tid / YT) * 4) = mp;
   };
 
   int64_t tile = rbi;
@@ -234,31 +231,121 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     gload(tile + nrb);   // past the end: re-reads tile 0, never used
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* base = lds + buf * BUF;
-    const f32x16 z0 = gemm1(base, 0);
-    const f32x16 z1 = gemm1(base, 1);
-    f16x8 rh0[2], rl0[2], rh1[2], rl1[2];
-    post(z0, rh0, rl0);
-    gemm2(base, 0, rh0, rl0);
-    lstore(buf ^ 1);
-    post(z1, rh1, rl1);
-    gemm2(base, 1, rh1, rl1);
+    float a2[2] = {0.f, 0.f};   // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
+#pragma unroll
+    for (int sub = 0; sub < kTileRows / 64; ++sub) {
+    const int ro = 64 * sub;
+    f32x4v Z[4][2];
+    // LDS fragments are fetched one step ahead of the MFMAs that consume them (the scheduler
+    // barriers keep the fetches where they are written), so that their latency is not exposed
+    f16x8 ah[2][KS], al[2][KS];
+    auto load_a = [&](int rt, int slot) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (ro + 16 * rt + ln) * SA + (((4 * ks + g) ^ swz(16 * rt + ln)) << 4);
+        ah[slot][ks] = *reinterpret_cast<const f16x8*>(base + off);
+        al[slot][ks] = *reinterpret_cast<const f16x8*>(base + IMG + off);
+      }
+    };
+    f16x8 xh[3], xl[3];
+    auto load_x = [&](int m, int ft, int slot) {
+      const int trow = ro + 32 * m + 4 * g + (ln >> 2);   // swz(trow + 16) == swz(trow)
+      const int off0 = trow * SA + (((2 * ft + ((ln & 3) >> 1)) ^ swz(trow)) << 4) + 8 * (ln & 1);
+      const int off1 = off0 + 16 * SA;
+      const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
+      const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
+      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + IMG + off0));
+      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + IMG + off1));
+      xh[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+      xl[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // GEMM1, then r' = z' (u / t) + (u y - u b0): scaled residuals of this wave's 64 rows x 32 chains
+    load_a(0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const f32x4v yv = *reinterpret_cast<const f32x4v*>(base + 2 * IMG + (ro + 16 * rt + 4 * g) * 4);
+      const f32x4v mv = *reinterpret_cast<const f32x4v*>(base + 2 * IMG + kTileRows * 4 + (ro + 16 * rt + 4 * g) * 4);
+      if (rt < 3) load_a(rt + 1, (rt + 1) & 1);
+      else { load_x(0, 0, 0); load_x(0, 1, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4v z[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[ct][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
+          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
+          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w2[ct][ks], z[ct], 0, 0, 0);
+          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w3[ct][ks], z[ct], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Z[rt][ct][i] = fmaf(z[ct][i], c1[ct], fmaf(mv[i], nb0[ct], yv[i]));
+    }
+    // GEMM2: G' += R'^T X' over the two 32-row pairs
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f16x8 rh[2], rl[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float q0 = Z[2 * m + (j >> 2)][ct][j & 3], q1 = Z[2 * m + (j >> 2)][ct][(j & 3) + 1];
+          a2[ct] = fmaf(q0, q0, a2[ct]);
+          a2[ct] = fmaf(q1, q1, a2[ct]);
+          split_pair(q0, q1, hw[j >> 1], lw[j >> 1]);
+        }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        rh[ct] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+        rl[ct] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+      }
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        const int step = m * FT + ft, cur = step % 3;     // fragments are fetched two steps ahead
+        if (step + 2 < 2 * FT) load_x((step + 2) / FT, (step + 2) % FT, (step + 2) % 3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ct], xh[cur], G[ct][ft], 0, 0, 0);
+          G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl[ct], xh[cur], G[ct][ft], 0, 0, 0);
+          G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ct], xl[cur], G[ct][ft], 0, 0, 0);
+        }
+      }
+    }
+    }
+    s2[0] += a2[0];
+    s2[1] += a2[1];
+    lstore(buf ^ 1);     // as late as possible: the whole tile's arithmetic covers the HBM latency of gload
     __syncthreads();
     buf ^= 1;
   }
 
-  s2 += __shfl_xor(s2, 32, 64);
-  if (cvalid && h == 0) {
-    float* p = partials + ((int64_t)rbi * C + chain) * (D + 2);
-    p[0] = s2;
-    p[1] = 0.f;   // S1 comes from the packed data sums (finalize)
-  }
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = cbi * kChainsPerBlock + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (c < C) partials[((int64_t)rbi * C + c) * (D + 2) + 2 + 32 * nt + r] = G[nt][i];
+  for (int ct = 0; ct < 2; ++ct) {
+    float v = s2[ct];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int chain = cbase + 16 * ct + ln;
+    if (chain < C && g == 0) {
+      float* p = partials + ((int64_t)rbi * C + chain) * (D + 2);
+      p[0] = v;
+      p[1] = 0.f;   // S1 comes from the packed data sums (finalize)
     }
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = cbase + 16 * ct + 4 * g + i;
+        if (c < C) partials[((int64_t)rbi * C + c) * (D + 2) + 2 + 16 * ft + ln] = G[ct][ft][i];
+      }
+  }
 }
 
 // ---- pack: column statistics (two-stage, fixed order) then the split ----
@@ -335,11 +422,11 @@ __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* 
 
 template <int D>
 __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n,
-                                  int64_t n_pad, unsigned char* __restrict__ packed) {
+                                int64_t n_pad, unsigned char* __restrict__ packed) {
   constexpr int TPR = D / 8;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   unsigned char* planes = packed + kHeader;
-  unsigned char* ext = planes + (int64_t)2 * n_pad * D * 2;
+  unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
   const int64_t total = n_pad * TPR;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -368,33 +455,22 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
     const int64_t plane = n_pad * D * 2;
     *reinterpret_cast<f16x8*>(planes + off) = fh;
     *reinterpret_cast<f16x8*>(planes + plane + off) = fl;
-    if (scol == 0) {
-      bf16x8 ye;
-      float rem = ok ? y[row] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const __bf16 pz = (__bf16)rem;
-        ye[j] = pz;
-        rem -= (float)pz;
-        ye[3 + j] = (__bf16)(ok ? 1.f : 0.f);
-      }
-      ye[6] = (__bf16)0.f;
-      ye[7] = (__bf16)0.f;
-      *reinterpret_cast<bf16x8*>(ext + row * 16) = ye;
-    }
+    if (scol == 0) *reinterpret_cast<float*>(yplane + row * 4) = ok ? y[row] : 0.f;
   }
 }
 
-// finalize: fixed-order reduction over row blocks (double) + scaling; S1 from the packed data sums
-__global__ void linreg_f16_finalize(const float* __restrict__ partials, int nb, int64_t n, int d,
-                                      const unsigned char* __restrict__ packed, const float* __restrict__ theta,
-                                      int C, float* __restrict__ logp, float* __restrict__ grad) {
+// finalize: fixed-order reduction over row blocks (double) + undoing the scales; S1 from the packed data sums
+__global__ void linreg_f16_finalize(const float* __restrict__ partials, const float* __restrict__ ublk, int cpb,
+                                    int nb, int64_t n, int d, const unsigned char* __restrict__ packed,
+                                    const float* __restrict__ theta, int C, float* __restrict__ logp,
+                                    float* __restrict__ grad) {
   const int q2 = d + 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= C * q2) return;
   const int c = idx / q2, q = idx - c * q2;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const float* th = theta + (int64_t)c * q2;
+  const double u = (double)ublk[c / cpb];
   double s = 0.0;
   if (q == 1) {
     s = hdr->ysum - (double)n * (double)th[0];
@@ -405,14 +481,13 @@ __global__ void linreg_f16_finalize(const float* __restrict__ partials, int nb, 
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   if (q == 0) {
+    s /= u * u;       // S2' = u^2 S2
     logp[c] = (float)(-0.5 * s * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s * inv2 / sc);
   } else if (grad) {
-    if (q >= 2) {   // undo the scales of the gradient GEMM: G' = u_c * s_d * G
-      float amax = 0.f;
-      for (int j = 0; j < d; ++j) amax = fmaxf(amax, fabsf(scaled_weight(th[1 + j], hdr->colscale[j])));
+    if (q >= 2) {     // G'_d = u s_d G_d
       const double cs = (double)hdr->colscale[q - 2];
-      s = cs > 0.0 ? s / ((double)resid_scale(amax, th[0], hdr->ymax, d) * cs) : s * 0.0;
+      s = cs > 0.0 ? s / (u * cs) : s * 0.0;
     }
     grad[(int64_t)c * q2 + (q - 1)] = (float)(s * inv2);
   }
@@ -425,7 +500,7 @@ constexpr int kStatBlocks = 1024;
 
 size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
   const int64_t np = pad_rows(n);
-  return (size_t)(kHeader + np * d * 4 + np * 16);
+  return (size_t)(kHeader + np * d * 4 + np * 4);
 }
 
 // scratch for the column statistics of the pack step (bytes)
@@ -461,25 +536,36 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
 }
 
 int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
-                            float* grad, float* ws, hipStream_t s) {
+                          float* grad, float* ws, hipStream_t s) {
   if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
   if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
-  const int ncb = bvi_ceil_div(c, kChainsPerBlock);
-  int per8 = 32 / ncb;
+  constexpr int cpb = 32 * kWaves;
+  const int ncb = bvi_ceil_div(c, cpb);
+  int per8 = (kMaxRowBlocks / 8) / ncb;      // one workgroup per CU: ncb * nrb = 256 while ncb <= 32
   if (per8 < 1) per8 = 1;
   const int nrb = 8 * per8;
   dim3 grid(ncb * nrb);
   const unsigned char* pk = (const unsigned char*)packed;
-  const size_t lds = 2 * (size_t)(2 * kTileRows * (2 * d + 16) + kTileRows * 16);
-  if (d == 64) {
-    hipLaunchKernelGGL((linreg_f16_kernel<64, 4>), grid, dim3(kThreads), lds, s, pk, n, theta, c, ncb, nrb, ws);
-  } else {
-    hipLaunchKernelGGL((linreg_f16_kernel<32, 4>), grid, dim3(kThreads), lds, s, pk, n, theta, c, ncb, nrb, ws);
+  // workspace: partials [nrb][c][d+2], then one residual scale per chain block
+  float* ublk = ws + (size_t)nrb * c * (d + 2);
+  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * d + 2 * kTileRows * 4);
+  static bool lds_ok[2] = {false, false};   // > 64 KB of dynamic LDS has to be allowed once per kernel
+  if (!lds_ok[d == 64]) {
+    const void* fn = d == 64 ? (const void*)&linreg_f16_kernel<64, kWaves> : (const void*)&linreg_f16_kernel<32, kWaves>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_ok[d == 64] = true;
   }
+  if (d == 64)
+    hipLaunchKernelGGL((linreg_f16_kernel<64, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, theta, c, ncb, nrb,
+                       ws, ublk);
+  else
+    hipLaunchKernelGGL((linreg_f16_kernel<32, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, theta, c, ncb, nrb,
+                       ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * (d + 2);
-  hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws, nrb, n,
-                     d, pk, theta, c, logp, grad);
+  hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws,
+                     (const float*)ublk, cpb, nrb, n, d, pk, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

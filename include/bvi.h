@@ -122,8 +122,12 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
  *                    precision BF16X6 (default) or BF16X3;
  *   BVI_PACK_F16     per-column power-of-two scales, data sums and max|y| in a 1024-B header, f16
  *                    hi/lo planes [2][n_pad][d] of the scaled X (both GEMMs run on the f16 matrix
- *                    cores with 2-piece operands) + the row extension; precision must be AUTO.
- * n_pad = n rounded up to 64 with zero rows.  bvi_linreg_pack needs bvi_linreg_pack_scratch_bytes
+ *                    cores; X in 2 pieces, the weights in 3, the residuals in 2) + y[n_pad] in f32,
+ *                    n_pad = n rounded up to 128; precision must be AUTO.  Gradient error at the level of
+ *                    the exact-f32 kernel's.  Limits: an element below 2^-16 of its column's largest
+ *                    magnitude loses low bits (absolute error <= 2^-39 of that maximum); X is held to
+ *                    within 1 f32 ulp, exactly if it has <= 22 significant bits.
+ * Padding rows are zero (BF16X3: n_pad = n rounded up to 64).  bvi_linreg_pack needs bvi_linreg_pack_scratch_bytes
  * of workspace (0 for BF16X3). */
 #define BVI_PACK_BF16X3 0
 #define BVI_PACK_F16 1
