@@ -1,0 +1,222 @@
+"""GPU: the hot path at the BASELINE.json sizes (10M x 64 regression with 1024 chains, 100M-row
+mixtures), checked through properties that do not need a CPU pass over the data: sums over row
+shards add, a rescaling of the problem rescales the answer in closed form, and -- as an independent
+full-size reference -- float64 torch evaluations on the device (sufficient statistics for the
+Gaussian families, a direct chunked evaluation for the mixture).  Tolerances as in parity_util."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from parity_util import RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def nat(gpu_device):
+    from bayes_vi_amd import _native
+    _native.lib()
+    return _native
+
+
+@pytest.fixture(scope='module')
+def ws(nat, gpu_device):
+    return nat.Workspace(torch.device(gpu_device))
+
+
+def _close(a, b, scale, rtol=RTOL, what=''):
+    err = (a.double() - b.double()).abs()
+    tol = rtol * scale
+    assert bool((err <= tol).all()), '%s: worst err/tol %.3g' % (what, float((err / tol).max()))
+
+
+@pytest.fixture(scope='module')
+def regression_10m(gpu_device):
+    n, d, c = 10_000_000, 64, 1024
+    g = torch.Generator(device=gpu_device); g.manual_seed(1234)
+    X = torch.empty(n, d, device=gpu_device)
+    for s in range(0, n, 1 << 20):
+        X[s:s + (1 << 20)].normal_(generator=g)
+    w = torch.randn(d, generator=g, device=gpu_device)
+    y = 0.5 + X @ w + torch.randn(n, generator=g, device=gpu_device)
+    th = torch.cat([0.5 + 0.01 * torch.randn(c, 1, generator=g, device=gpu_device),
+                    w + 0.01 * torch.randn(c, d, generator=g, device=gpu_device),
+                    1 + 0.2 * torch.rand(c, 1, generator=g, device=gpu_device)], -1).contiguous()
+    # float64 sufficient statistics of the augmented design [1, X]: an independent full-size reference
+    A = torch.zeros(d + 1, d + 1, dtype=torch.float64, device=gpu_device)
+    b = torch.zeros(d + 1, dtype=torch.float64, device=gpu_device)
+    yy = torch.zeros((), dtype=torch.float64, device=gpu_device)
+    absx = torch.zeros(d + 1, dtype=torch.float64, device=gpu_device)
+    for s in range(0, n, 1 << 20):
+        Xa = torch.cat([torch.ones(min(1 << 20, n - s), 1, dtype=torch.float64, device=gpu_device),
+                        X[s:s + (1 << 20)].double()], 1)
+        yc = y[s:s + (1 << 20)].double()
+        A += Xa.T @ Xa; b += Xa.T @ yc; yy += yc @ yc; absx += Xa.abs().sum(0)
+    return dict(n=n, d=d, c=c, X=X, y=y, th=th, A=A, b=b, yy=yy, absx=absx)
+
+
+def _reference_from_stats(r, th):
+    n, d = r['n'], r['d']
+    beta = th[:, :d + 1].double(); sc = th[:, d + 1].double()
+    s2 = r['yy'] - 2 * beta @ r['b'] + ((beta @ r['A']) * beta).sum(-1)
+    gb = (r['b'][None] - beta @ r['A']) / sc[:, None] ** 2
+    lp = -0.5 * s2 / sc ** 2 - n * torch.log(sc) - 0.5 * n * math.log(2 * math.pi)
+    gs = -n / sc + s2 / sc ** 3
+    # size of the terms each gradient entry sums: sum_i |r_i| |x_id| ~ sqrt(2/pi) sd(r) sum_i |x_id|
+    term = math.sqrt(2 / math.pi) * torch.sqrt(s2 / n)[:, None] * r['absx'][None] / sc[:, None] ** 2
+    return lp, torch.cat([gb, gs[:, None]], -1), torch.cat([term, (s2 / sc ** 3 + n / sc)[:, None]], -1)
+
+
+def test_regression_10m_rows_1024_chains_against_float64_statistics(nat, ws, regression_10m):
+    """BASELINE configs[1] in full: the f16-piece matrix-core kernel on 10M x 64 with 1024 chains
+    against the float64 sufficient-statistics evaluation; the exact-f32 kernel on 64 of the chains."""
+    r = regression_10m
+    n, d, th = r['n'], r['d'], r['th']
+    ref_lp, ref_g, term = _reference_from_stats(r, th)
+    pk = nat.linreg_pack(r['X'], r['y'], fmt=nat.PACK_F16)
+    lp, g = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
+    assert bool(torch.isfinite(lp).all()) and bool(torch.isfinite(g).all())
+    _close(lp, ref_lp, ref_lp.abs(), what='logp f16 pieces')
+    gmax = ref_g.abs().max(-1, keepdim=True).values
+    _close(g, ref_g, gmax + 3e-2 * term, what='grad f16 pieces')
+    lp32, g32 = nat.linreg_logp_grad(r['X'], r['y'], th[:64].contiguous(), ws, precision=nat.PREC_F32)
+    _close(lp32, ref_lp[:64], ref_lp[:64].abs(), what='logp f32')
+    _close(g32, ref_g[:64], gmax[:64] + 3e-2 * term[:64], what='grad f32')
+    # determinism at full size
+    lp2, g2 = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
+    assert torch.equal(lp, lp2) and torch.equal(g, g2)
+    r['full'] = (lp, g)
+
+
+def test_regression_10m_row_shards_add(nat, ws, regression_10m):
+    """The outputs are likelihood-only sums, so two row shards -- packed separately, with their own
+    column scales -- must add up to the full-data result (what the all-reduce over GPUs relies on)."""
+    r = regression_10m
+    n, d, th = r['n'], r['d'], r['th']
+    if 'full' not in r:
+        pk = nat.linreg_pack(r['X'], r['y'], fmt=nat.PACK_F16)
+        r['full'] = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
+    lp, g = r['full']
+    cut = 3_700_001
+    parts = []
+    for lo, hi in ((0, cut), (cut, n)):
+        Xs, ys = r['X'][lo:hi], r['y'][lo:hi]
+        pk = nat.linreg_pack(Xs, ys, fmt=nat.PACK_F16)
+        parts.append(nat.linreg_packed_logp_grad(pk, hi - lo, d, th, ws, fmt=nat.PACK_F16))
+        del pk
+    lps = parts[0][0].double() + parts[1][0].double()
+    gs = parts[0][1].double() + parts[1][1].double()
+    _, ref_g, term = _reference_from_stats(r, th)
+    _close(lps, lp, lp.abs(), what='logp shards')
+    _close(gs, g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='grad shards')
+
+
+def test_regression_10m_rescaling_property(nat, ws, regression_10m):
+    """y -> a y, (b0, w, scale) -> a (b0, w, scale) leaves every standardised residual unchanged:
+    logp shifts by -n log a and the gradient scales by 1/a (a = 3: not a power of two, so every
+    operand's bits change)."""
+    r = regression_10m
+    n, d, th = r['n'], r['d'], r['th'][:256].contiguous()
+    a = 3.0
+    pk = nat.linreg_pack(r['X'], r['y'], fmt=nat.PACK_F16)
+    lp, g = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
+    del pk
+    ya = (r['y'] * a).contiguous()
+    pka = nat.linreg_pack(r['X'], ya, fmt=nat.PACK_F16)
+    lpa, ga = nat.linreg_packed_logp_grad(pka, n, d, (th * a).contiguous(), ws, fmt=nat.PACK_F16)
+    _, ref_g, term = _reference_from_stats(r, r['th'][:256])
+    _close(lpa.double() + n * math.log(a), lp, lp.abs(), rtol=2 * RTOL, what='logp rescaled')
+    # y, theta were re-rounded to f32 after scaling: allow the f32 input rounding on top (2x)
+    _close(ga.double() * a, g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, rtol=3 * RTOL,
+           what='grad rescaled')
+
+
+def test_mixture_100m_rows(nat, ws, gpu_device):
+    """BASELINE configs[2] size: K = 8 mixture over 100M rows.  Row shards (cut at an odd row, so the
+    second shard is not 16-byte aligned) add up; two chains against a chunked float64 evaluation."""
+    n, k, c = 100_000_000, 8, 16
+    g = torch.Generator(device=gpu_device); g.manual_seed(7)
+    locs = torch.linspace(-20, 20, k, device=gpu_device)
+    y = torch.empty(n, device=gpu_device)
+    for s in range(0, n, 1 << 24):
+        m = min(1 << 24, n - s)
+        y[s:s + m] = locs[torch.randint(0, k, (m,), generator=g, device=gpu_device)] + \
+            torch.randn(m, generator=g, device=gpu_device)
+    th = torch.cat([(1.0 / k) * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device)),
+                    locs + 0.1 * torch.randn(c, k, generator=g, device=gpu_device),
+                    1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device)], -1).contiguous()
+    lp, gr = nat.gmm1d_logp_grad(y, th, k, ws)
+    cut = 41_234_567
+    a = nat.gmm1d_logp_grad(y[:cut], th, k, ws)
+    b = nat.gmm1d_logp_grad(y[cut:], th, k, ws)
+    # float64 reference for two chains, chunked
+    t2 = th[:2].double()
+    wgt, mu, sc = t2[:, :k], t2[:, k:2 * k], t2[:, 2 * k:]
+    ref_lp = torch.zeros(2, dtype=torch.float64, device=gpu_device)
+    ref_g = torch.zeros(2, 3 * k, dtype=torch.float64, device=gpu_device)
+    absg = torch.zeros(2, 3 * k, dtype=torch.float64, device=gpu_device)
+    logw = torch.log(wgt / wgt.sum(-1, keepdim=True))
+    for s in range(0, n, 1 << 22):
+        yc = y[s:s + (1 << 22)].double()[None, :, None]
+        u = (yc - mu[:, None]) / sc[:, None]
+        e = logw[:, None] - torch.log(sc[:, None]) - 0.5 * math.log(2 * math.pi) - 0.5 * u * u
+        lse = torch.logsumexp(e, -1)
+        rho = torch.exp(e - lse[..., None])
+        ref_lp += lse.sum(-1)
+        parts = [rho / wgt[:, None] - 1.0 / wgt.sum(-1)[:, None, None], rho * u / sc[:, None],
+                 rho * (u * u - 1) / sc[:, None]]
+        ref_g += torch.cat([p.sum(1) for p in parts], -1)
+        absg += torch.cat([p.abs().sum(1) for p in parts], -1)
+    _close(lp[:2], ref_lp, ref_lp.abs(), what='mixture logp')
+    _close(gr[:2], ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg, what='mixture grad')
+    _close(a[0].double() + b[0].double(), lp, lp.abs(), what='mixture logp shards')
+    scale = gr.abs().max(-1, keepdim=True).values.double() + 3e-2 * absg.max(0).values[None]
+    _close(a[1].double() + b[1].double(), gr, scale, what='mixture grad shards')
+
+
+def test_normal_100m_rows(nat, ws, gpu_device):
+    n, c = 100_000_000, 64
+    g = torch.Generator(device=gpu_device); g.manual_seed(9)
+    y = torch.empty(n, device=gpu_device).normal_(7.0, 3.0, generator=g)
+    th = torch.stack([7 + 0.01 * torch.randn(c, generator=g, device=gpu_device),
+                      3 + 0.1 * torch.rand(c, generator=g, device=gpu_device)], -1).contiguous()
+    lp, gr = nat.normal_iid_logp_grad(y, th, ws)
+    s0 = torch.zeros((), dtype=torch.float64, device=gpu_device); s1 = s0.clone(); s2 = s0.clone(); sa = s0.clone()
+    for s in range(0, n, 1 << 24):
+        yc = y[s:s + (1 << 24)].double()
+        s1 += yc.sum(); s2 += (yc * yc).sum(); sa += (yc - 7.0).abs().sum()
+    mu, sc = th[:, 0].double(), th[:, 1].double()
+    r1 = s1 - n * mu
+    r2 = s2 - 2 * mu * s1 + n * mu * mu
+    ref_lp = -0.5 * r2 / sc ** 2 - n * torch.log(sc) - 0.5 * n * math.log(2 * math.pi)
+    ref_g = torch.stack([r1 / sc ** 2, -n / sc + r2 / sc ** 3], -1)
+    term = torch.stack([sa / sc ** 2, r2 / sc ** 3 + n / sc], -1)
+    _close(lp, ref_lp, ref_lp.abs(), what='normal logp')
+    _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='normal grad')
+
+
+def test_fullcov_mixture_1m_rows_shards_add(nat, ws, gpu_device):
+    """BASELINE configs[3] shape (D = 32, K = 16, full covariance): shard additivity at 1M rows."""
+    n, d, k, c = 1_000_000, 32, 16, 4
+    g = torch.Generator(device=gpu_device); g.manual_seed(11)
+    centers = 4 * torch.randn(k, d, generator=g, device=gpu_device)
+    Y = (centers[torch.randint(0, k, (n,), generator=g, device=gpu_device)]
+         + torch.randn(n, d, generator=g, device=gpu_device)).contiguous()
+    L = torch.eye(d, device=gpu_device)[None, None] * (1 + 0.1 * torch.rand(c, k, 1, 1, generator=g, device=gpu_device)) \
+        + 0.02 * torch.tril(torch.randn(c, k, d, d, generator=g, device=gpu_device), -1)
+    th = torch.cat([(1.0 / k) * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device)),
+                    (centers[None] + 0.05 * torch.randn(c, k, d, generator=g, device=gpu_device)).reshape(c, -1),
+                    L.reshape(c, -1)], -1).contiguous()
+    lp, gr = nat.gmm_fullcov_logp_grad(Y, th, k, ws)
+    cut = 333_337
+    a = nat.gmm_fullcov_logp_grad(Y[:cut].contiguous(), th, k, ws)
+    b = nat.gmm_fullcov_logp_grad(Y[cut:].contiguous(), th, k, ws)
+    assert bool(torch.isfinite(lp).all()) and bool(torch.isfinite(gr).all())
+    _close(a[0].double() + b[0].double(), lp, lp.abs(), what='fullcov logp shards')
+    # per-entry term scale is not available without a second pass: judge against the largest entry of the
+    # chain's gradient block (weights | locs | scale_tril)
+    for lo, hi in ((0, k), (k, k + k * d), (k + k * d, th.shape[1])):
+        scale = gr[:, lo:hi].abs().max(-1, keepdim=True).values.double()
+        _close((a[1].double() + b[1].double())[:, lo:hi], gr[:, lo:hi], scale, rtol=3 * RTOL, what='fullcov grad shards')

@@ -269,6 +269,26 @@ def test_linreg_errors(nat, ws, gpu_device):
         nat.linreg_logp_grad(X.cpu(), y, th, ws)
 
 
+def test_streaming_kernels_accept_unaligned_data(nat, ws, gpu_device):
+    """A dataset that starts 4 bytes into an allocation (a row shard cut at an odd row): the
+    16-byte loads are replaced by guarded scalar ones, the result is unchanged."""
+    rng = np.random.default_rng(77)
+    n = 5003
+    y = rng.normal(2, 3, n + 1).astype(np.float32)
+    yd = dev(y, gpu_device)[1:]
+    assert yd.data_ptr() % 16 != 0
+    th = np.stack([rng.normal(2, .1, 5), rng.uniform(2, 4, 5)], -1).astype(np.float32)
+    lp, g = nat.normal_iid_logp_grad(yd, dev(th, gpu_device), ws)
+    rlp, rg = cf.normal_iid(y[1:], th)
+    assert_logp_close(lp.cpu().numpy(), rlp); assert_grad_close(g.cpu().numpy(), rg)
+    k = 3
+    thm = np.concatenate([rng.dirichlet(np.ones(k) * 5, 4), np.array([-1., 2., 5.]) + rng.normal(0, .3, (4, k)),
+                          rng.uniform(2, 4, (4, k))], -1).astype(np.float32)
+    lp, g = nat.gmm1d_logp_grad(yd, dev(thm, gpu_device), k, ws)
+    rlp, rg = cf.gmm1d(y[1:], thm, k)
+    assert_logp_close(lp.cpu().numpy(), rlp); assert_grad_close(g.cpu().numpy(), rg)
+
+
 def test_nonfinite_parameters_propagate(nat, ws, gpu_device):
     y = dev(np.linspace(-1, 1, 100), gpu_device)
     th = dev([[0.0, -1.0], [float('nan'), 1.0], [0.0, 1.0]], gpu_device)

@@ -1,0 +1,34 @@
+"""Kernel time of the 1-D mixture and iid-Normal likelihoods at BASELINE configs[2] size (N = 100M, K = 8)."""
+import os, sys, argparse
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
+from bayes_vi_amd import _native as nat
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--rows', type=int, default=100_000_000)
+ap.add_argument('--k', type=int, default=8)
+a = ap.parse_args()
+dev = torch.device('cuda:0'); ws = nat.Workspace(dev)
+g = torch.Generator(device=dev); g.manual_seed(1)
+k = a.k
+locs = torch.linspace(-20, 20, k, device=dev)
+comp = torch.randint(0, k, (a.rows,), generator=g, device=dev)
+y = locs[comp] + torch.randn(a.rows, generator=g, device=dev)
+del comp
+for c in (1, 4, 16, 64, 256, 1024):
+    th = torch.cat([torch.full((c, k), 1.0 / k, device=dev) * (1 + 0.1 * torch.rand(c, k, generator=g, device=dev)),
+                    locs + 0.1 * torch.randn(c, k, generator=g, device=dev),
+                    1 + 0.1 * torch.rand(c, k, generator=g, device=dev)], -1).contiguous()
+    thn = torch.cat([0.1 * torch.randn(c, 1, generator=g, device=dev), 11 + torch.rand(c, 1, generator=g, device=dev)], -1).contiguous()
+    for name, fn in (('gmm1d', lambda: nat.gmm1d_logp_grad(y, th, k, ws)), ('normal', lambda: nat.normal_iid_logp_grad(y, thn, ws))):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        ts.sort(); med = ts[2]
+        print('%-6s rows=%d K=%d chains=%4d: %8.3f ms  %7.1f GB/s alg  %8.2f G row-chain-evals/s'
+              % (name, a.rows, k, c, med, 4.0 * a.rows / med / 1e6, a.rows * c / med / 1e6), flush=True)
