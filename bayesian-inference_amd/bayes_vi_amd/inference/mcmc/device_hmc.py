@@ -157,3 +157,63 @@ class FusedHamiltonianMonteCarloKernel:
                                            momenta[None] if momenta is not None else None,
                                            log_uniform[None] if log_uniform is not None else None)
         return z, state, {k: v[0] for k, v in tr.items()}
+
+
+class FusedNoUTurnSamplerKernel:
+    """NUTS with whole transitions -- and whole runs of transitions -- inside one kernel launch
+    (bvi_nuts_fused), one workgroup per chain.  Same algorithm and trace fields as
+    `samplers.NoUTurnSamplerKernel`; random numbers are Philox draws keyed by (seed; transition,
+    chain), so a run is reproducible from its seed."""
+    trace_names = ('is_accepted', 'target_log_prob', 'log_accept_ratio', 'step_size',
+                   'leapfrogs_taken', 'has_divergence', 'energy')
+    supports_many_steps = True
+
+    def __init__(self, posterior, family, step_size=0.01, max_tree_depth=5, max_energy_diff=1000.0, seed=0):
+        self.posterior = posterior
+        self.family = family
+        self.blocks = posterior.device_blocks()
+        self.nb = len(self.blocks)
+        self.step_size = float(step_size)
+        self.max_tree_depth = int(max_tree_depth)
+        self.max_energy_diff = float(max_energy_diff)
+        self.seed = int(seed)
+        self.transition = 0
+
+    def _launch(self, z, g, lp, n_transitions, evaluate_initial, seed, outs=None):
+        fam, X, y, n, d, k = self.family
+        ptr = _native._ptr
+        outs = outs if outs is not None else (None,) * 6
+        _native.check(_native.lib().bvi_nuts_fused(
+            fam, ptr(X), ptr(y), n, d, k, self.blocks, self.nb, z.shape[0], self.step_size, None,
+            self.max_tree_depth, self.max_energy_diff, n_transitions, seed, self.transition,
+            1 if evaluate_initial else 0, ptr(z), ptr(g), ptr(lp), *[ptr(o) for o in outs], _native._stream()),
+            'bvi_nuts_fused')
+        self.transition += n_transitions
+
+    def bootstrap(self, z):
+        z = z.contiguous().to(torch.float32)
+        g = torch.empty_like(z)
+        lp = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        self._launch(z, g, lp, 0, True, self.seed)
+        return {'target_log_prob': lp, 'grad': g}
+
+    def many_steps(self, z, state, n, generator=None):
+        z = z.clone().contiguous()
+        lp = state['target_log_prob'].clone()
+        g = state['grad'].clone()
+        c, pu = z.shape
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=z.device)
+        zs, lps, lrs = f(n, c, pu), f(n, c), f(n, c)
+        moved = torch.empty(n, c, dtype=torch.uint8, device=z.device)
+        div = torch.empty(n, c, dtype=torch.uint8, device=z.device)
+        leaps = torch.empty(n, c, dtype=torch.int32, device=z.device)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        self._launch(z, g, lp, n, False, seed, (zs, lps, moved, lrs, leaps, div))
+        traces = {'is_accepted': moved.to(torch.bool), 'target_log_prob': lps, 'log_accept_ratio': lrs,
+                  'step_size': torch.full((n,), self.step_size, dtype=z.dtype),
+                  'leapfrogs_taken': leaps.to(torch.int64), 'has_divergence': div.to(torch.bool), 'energy': -lps}
+        return zs, z, {'target_log_prob': lp, 'grad': g}, traces
+
+    def one_step(self, z, state, generator=None):
+        zs, z, state, tr = self.many_steps(z, state, 1, generator)
+        return z, state, {k: v[0] for k, v in tr.items()}

@@ -77,6 +77,15 @@ class NoUTurnSampler(TransitionKernel):
                                  'leapfrogs_taken', 'has_divergence', 'energy']
 
     def _make(self, target):
+        # small dataset on the GPU with built-in priors / bijectors: whole transitions in one launch
+        post = getattr(target, '__self__', None)
+        if post is not None and hasattr(post, 'device_blocks') and post.likelihood.device.type == 'cuda' \
+                and self.unrolled_leapfrog_steps == 1 and self.max_tree_depth <= 10:
+            from .device_hmc import FusedNoUTurnSamplerKernel, fused_family
+            fam = fused_family(post)
+            if fam is not None:
+                return FusedNoUTurnSamplerKernel(post, fam, self.step_size, self.max_tree_depth,
+                                                 self.max_energy_diff)
         return samplers.NoUTurnSamplerKernel(target, self.step_size, self.max_tree_depth, self.max_energy_diff,
                                              self.unrolled_leapfrog_steps)
 

@@ -16,6 +16,15 @@
 // the raw sums; lane j turns them into d log lik / d theta_j, adds its prior score, and applies the
 // bijector chain rule.  Nothing leaves the chip between the first and the last transition except
 // the optional per-transition outputs.
+//
+// The same kernel runs the No-U-Turn sampler (ALGO = 1): the iterative tree doubling of
+// tfp.mcmc.NoUTurnSampler (transition_kernels.py:238-246) -- multinomial sampling inside a subtree,
+// biased progressive sampling between subtrees, U-turn checks against checkpoints of sub-tree ends,
+// divergence when the energy error exceeds max_energy_diff -- with one chain per workgroup, so that
+// the data-dependent tree depth is ordinary uniform control flow.  Same algorithm, step for step, as
+// the batched host kernel (inference/mcmc/samplers.py::NoUTurnSamplerKernel); random numbers are
+// Philox draws: momenta on stream 0, (direction, subtree-accept) per depth on stream 2, the
+// multinomial uniform per leaf on stream 3.
 #include "bvi_common.h"
 #include "posterior_device.h"
 
@@ -23,6 +32,7 @@ namespace {
 
 constexpr int kMaxP = 64;
 constexpr int kMaxQ = 3 * 8 + 1;
+constexpr int kMaxDepth = 10;
 
 struct FusedArgs {
   const float* X;
@@ -44,7 +54,17 @@ struct FusedArgs {
   float* lp_out;
   unsigned char* acc_out;
   float* lr_out;
+  int max_depth;          // NUTS only
+  float max_energy_diff;
+  int* leap_out;
+  unsigned char* div_out;
 };
+
+__device__ __forceinline__ float log_add_exp(float a, float b) {
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -53,12 +73,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // FAM: BVI_FAMILY_*; NP: padded feature count (regression) or component count (mixture)
-template <int FAM, int NP>
+template <int FAM, int NP, int ALGO>
 __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) {
   constexpr int Q = FAM == BVI_FAMILY_NORMAL_IID ? 2 : FAM == BVI_FAMILY_LINREG ? NP + 2 : 3 * NP + 1;
   constexpr int PF = FAM == BVI_FAMILY_NORMAL_IID ? 2 : FAM == BVI_FAMILY_LINREG ? NP + 2 : 3 * NP;
   __shared__ float sh_z[kMaxP], sh_theta[kMaxP], sh_gth[kMaxP];
   __shared__ float sh_part[4][kMaxQ];
+  __shared__ float sh_ckq[ALGO == 1 ? kMaxDepth + 1 : 1][kMaxP], sh_ckp[ALGO == 1 ? kMaxDepth + 1 : 1][kMaxP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
   const int c = blockIdx.x;
@@ -90,10 +111,10 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
   float gj = zl ? a.g[(int64_t)c * Pu + lane] : 0.f;
   float lp = a.lp[c];
 
-  // log pi(z) and its gradient at the current zj; every thread of the workgroup takes part
-  auto evaluate = [&](float& lp_out, float& g_out) {
+  // log pi and its gradient at the position whose element j is zq; every thread of the workgroup takes part
+  auto evaluate = [&](float zq, float& lp_out, float& g_out) {
     __syncthreads();                       // previous readers of the LDS arrays are done
-    if (wave == 0 && zl) sh_z[lane] = zj;
+    if (wave == 0 && zl) sh_z[lane] = zq;
     __syncthreads();
     // theta_j = f(z)_j and this element's share of the forward log-det-Jacobian
     float th_j = 0.f, fl_j = 0.f;
@@ -261,53 +282,147 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
         gz = t * (sh_gth[z_toff + z_j] - inner) + 1.f - (float)z_size * t;
       } else {
         const float gt = sh_gth[z_toff + z_j];
-        if (z_bij == BVI_BIJ_SOFTPLUS) gz = gt * sigmoidf(zj) + sigmoidf(-zj);
-        else if (z_bij == BVI_BIJ_EXP) gz = gt * expf(zj) + 1.f;
+        if (z_bij == BVI_BIJ_SOFTPLUS) gz = gt * sigmoidf(zq) + sigmoidf(-zq);
+        else if (z_bij == BVI_BIJ_EXP) gz = gt * expf(zq) + 1.f;
         else gz = gt;
       }
     }
     g_out = gz;
   };
 
-  if (a.evaluate_initial) evaluate(lp, gj);
+  if (a.evaluate_initial) evaluate(zj, lp, gj);
   const float eps = a.eps_chain ? a.eps_chain[c] : a.eps;
 
-  for (int t = 0; t < a.T; ++t) {
-    const uint64_t step = a.step0 + (uint64_t)t;
-    float pj = 0.f;
-    if (zl) {
-      if (a.momenta_in) {
-        pj = a.momenta_in[((int64_t)t * a.C + c) * Pu + lane];
-      } else {
-        float v[4];
-        normal4(draw(a.seed, step, c, lane >> 2, 0), v);
-        pj = v[lane & 3];
+  if constexpr (ALGO == 0) {
+    for (int t = 0; t < a.T; ++t) {
+      const uint64_t step = a.step0 + (uint64_t)t;
+      float pj = 0.f;
+      if (zl) {
+        if (a.momenta_in) {
+          pj = a.momenta_in[((int64_t)t * a.C + c) * Pu + lane];
+        } else {
+          float v[4];
+          normal4(draw(a.seed, step, c, lane >> 2, 0), v);
+          pj = v[lane & 3];
+        }
+      }
+      const float z0 = zj, g0 = gj, lp0 = lp;
+      const float k0 = wave_sum(0.5f * pj * pj);
+      for (int l = 0; l < a.L; ++l) {
+        pj = fmaf(0.5f * eps, gj, pj);
+        zj = fmaf(eps, pj, zj);
+        evaluate(zj, lp, gj);
+        pj = fmaf(0.5f * eps, gj, pj);
+      }
+      const float k1 = wave_sum(0.5f * pj * pj);
+      float lr = (lp - k1) - (lp0 - k0);
+      if (!isfinite(lr)) lr = -INFINITY;
+      const float lu = a.log_u_in ? a.log_u_in[(int64_t)t * a.C + c] : logf(u01(draw(a.seed, step, c, 0, 1).x));
+      const bool acc = lu < lr;
+      if (!acc) {
+        zj = z0;
+        gj = g0;
+        lp = lp0;
+      }
+      if (wave == 0) {
+        if (a.z_out && zl) a.z_out[((int64_t)t * a.C + c) * Pu + lane] = zj;
+        if (lane == 0) {
+          if (a.lp_out) a.lp_out[(int64_t)t * a.C + c] = lp;
+          if (a.acc_out) a.acc_out[(int64_t)t * a.C + c] = acc ? 1 : 0;
+          if (a.lr_out) a.lr_out[(int64_t)t * a.C + c] = lr;
+        }
       }
     }
-    const float z0 = zj, g0 = gj, lp0 = lp;
-    const float k0 = wave_sum(0.5f * pj * pj);
-    for (int l = 0; l < a.L; ++l) {
-      pj = fmaf(0.5f * eps, gj, pj);
-      zj = fmaf(eps, pj, zj);
-      evaluate(lp, gj);
-      pj = fmaf(0.5f * eps, gj, pj);
-    }
-    const float k1 = wave_sum(0.5f * pj * pj);
-    float lr = (lp - k1) - (lp0 - k0);
-    if (!isfinite(lr)) lr = -INFINITY;
-    const float lu = a.log_u_in ? a.log_u_in[(int64_t)t * a.C + c] : logf(u01(draw(a.seed, step, c, 0, 1).x));
-    const bool acc = lu < lr;
-    if (!acc) {
-      zj = z0;
-      gj = g0;
-      lp = lp0;
-    }
-    if (wave == 0) {
-      if (a.z_out && zl) a.z_out[((int64_t)t * a.C + c) * Pu + lane] = zj;
-      if (lane == 0) {
-        if (a.lp_out) a.lp_out[(int64_t)t * a.C + c] = lp;
-        if (a.acc_out) a.acc_out[(int64_t)t * a.C + c] = acc ? 1 : 0;
-        if (a.lr_out) a.lr_out[(int64_t)t * a.C + c] = lr;
+  } else {
+    // sum_j a_j b_j over the chain's elements (lanes beyond Pu hold zeros)
+    auto turning = [&](float aq, float ap, float bq, float bp) {
+      const float dq = bq - aq;
+      return wave_sum(dq * ap) <= 0.f || wave_sum(dq * bp) <= 0.f;
+    };
+    for (int t = 0; t < a.T; ++t) {
+      const uint64_t step = a.step0 + (uint64_t)t;
+      float p0 = 0.f;
+      if (zl) {
+        float v[4];
+        normal4(draw(a.seed, step, c, lane >> 2, 0), v);
+        p0 = v[lane & 3];
+      }
+      const float h0 = -lp + wave_sum(0.5f * p0 * p0);
+      float ql = zj, pl = p0, gl = gj, qr = zj, pr = p0, gr = gj;     // trajectory ends (left = backward in time)
+      float log_w = 0.f, sum_acc = 0.f;
+      int n_leap = 0, leaf_ctr = 0;
+      bool active = true, diverged = false, moved = false;
+      for (int depth = 0; depth < a.max_depth && active; ++depth) {
+        const U4 rd = draw(a.seed, step, c, depth, 2);
+        const bool go_right = u01(rd.x) < 0.5f;
+        const float log_u_sub = logf(u01(rd.y));
+        const float se = go_right ? eps : -eps;
+        float q = go_right ? qr : ql, p = go_right ? pr : pl, g = go_right ? gr : gl;
+        float sub_log_w = -INFINITY, sub_q = zj, sub_g = gj, sub_lp = lp;
+        bool sub_ok = true, turn_sub = false;
+        const int n_leaves = 1 << depth;
+        for (int leaf = 0; leaf < n_leaves; ++leaf) {
+          float lpq;
+          p = fmaf(0.5f * se, g, p);
+          q = fmaf(se, p, q);
+          evaluate(q, lpq, g);
+          p = fmaf(0.5f * se, g, p);
+          float dh = (-lpq + wave_sum(0.5f * p * p)) - h0;
+          if (!isfinite(dh)) dh = INFINITY;
+          const bool div_now = dh > a.max_energy_diff;
+          diverged |= div_now;
+          const bool ok = !div_now;
+          n_leap += 1;
+          sum_acc += expf(fminf(-dh, 0.f));
+          const float lw = -dh, new_w = log_add_exp(sub_log_w, lw);
+          const float log_ul = logf(u01(draw(a.seed, step, c, leaf_ctr++, 3).x));
+          if (ok && log_ul < lw - new_w) {       // multinomial sample within the subtree
+            sub_q = q;
+            sub_g = g;
+            sub_lp = lpq;
+          }
+          if (ok) sub_log_w = new_w;
+          // U-turn checks inside the subtree against checkpoints of the left ends of its sub-subtrees:
+          // slots popcount(leaf >> 1) - (trailing ones of leaf) + 1 .. popcount(leaf >> 1)
+          const int hi = __popc((unsigned)leaf >> 1);
+          if ((leaf & 1) == 0) {
+            if (lane < kMaxP) {
+              sh_ckq[hi][lane] = q;
+              sh_ckp[hi][lane] = p;
+            }
+          } else {
+            const int lo = hi - (__ffs(~leaf) - 1) + 1;
+            for (int k = lo; k <= hi; ++k) {
+              const float cq = sh_ckq[k][lane], cp = sh_ckp[k][lane];
+              // ordered in time: for leftward subtrees the checkpoint is the later end
+              const bool tn = go_right ? turning(cq, cp, q, p) : turning(q, p, cq, cp);
+              turn_sub |= ok && tn;
+            }
+          }
+          sub_ok = ok && !turn_sub;
+          if (!sub_ok) break;
+        }
+        if (go_right) { qr = q; pr = p; gr = g; } else { ql = q; pl = p; gl = g; }
+        const bool complete = sub_ok;
+        if (complete && log_u_sub < sub_log_w - log_w) {     // biased progressive sampling between subtrees
+          zj = sub_q;
+          gj = sub_g;
+          lp = sub_lp;
+          moved = true;
+        }
+        if (complete) log_w = log_add_exp(log_w, sub_log_w);
+        active = complete && !turning(ql, pl, qr, pr);
+      }
+      if (wave == 0) {
+        if (a.z_out && zl) a.z_out[((int64_t)t * a.C + c) * Pu + lane] = zj;
+        if (lane == 0) {
+          const int64_t o = (int64_t)t * a.C + c;
+          if (a.lp_out) a.lp_out[o] = lp;
+          if (a.acc_out) a.acc_out[o] = moved ? 1 : 0;
+          if (a.lr_out) a.lr_out[o] = logf(fmaxf(sum_acc / (float)(n_leap > 0 ? n_leap : 1), 1e-30f));
+          if (a.leap_out) a.leap_out[o] = n_leap;
+          if (a.div_out) a.div_out[o] = diverged ? 1 : 0;
+        }
       }
     }
   }
@@ -321,24 +436,18 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
 }
 
 template <int FAM, int NP>
-void launch(const Blocks& bl, const FusedArgs& a, int threads, hipStream_t s) {
-  hipLaunchKernelGGL((hmc_fused_kernel<FAM, NP>), dim3(a.C), dim3(threads), 0, s, bl, a);
+void launch(const Blocks& bl, const FusedArgs& a, int algo, int threads, hipStream_t s) {
+  if (algo == 0) hipLaunchKernelGGL((hmc_fused_kernel<FAM, NP, 0>), dim3(a.C), dim3(threads), 0, s, bl, a);
+  else hipLaunchKernelGGL((hmc_fused_kernel<FAM, NP, 1>), dim3(a.C), dim3(threads), 0, s, bl, a);
 }
 
-}  // namespace
-
-extern "C" int bvi_hmc_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
-                             const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
-                             const float* step_sizes, int n_leapfrog, int n_transitions, uint64_t seed,
-                             uint64_t first_step, int evaluate_initial, float* z, float* grad_z, float* lp,
-                             const float* momenta_in, const float* log_u_in, float* z_out, float* lp_out,
-                             unsigned char* accepted_out, float* log_ratio_out, void* stream) {
+// common argument checks and dispatch of both entry points
+int run_fused(int algo, int family, const float* X, const float* y, int64_t n, int d, int k,
+              const bvi_param_block* blocks, int n_blocks, FusedArgs& a, void* stream) {
   Blocks bl;
-  FusedArgs a;
   const int st = make_blocks(blocks, n_blocks, &bl, &a.P, &a.Pu);
   if (st != BVI_OK) return st;
-  if ((!y && n > 0) || n < 0 || n_chains < 1 || n_leapfrog < 1 || n_transitions < 0 || !z || !grad_z || !lp)
-    return BVI_ERR_ARG;
+  if ((!y && n > 0) || n < 0 || a.C < 1 || a.T < 0 || !a.z || !a.g || !a.lp) return BVI_ERR_ARG;
   int want_p;
   if (family == BVI_FAMILY_NORMAL_IID) want_p = 2;
   else if (family == BVI_FAMILY_LINREG) {
@@ -353,25 +462,57 @@ extern "C" int bvi_hmc_fused(int family, const float* X, const float* y, int64_t
     return BVI_ERR_UNSUPPORTED;
   }
   if (a.P != want_p || a.P > kMaxP) return BVI_ERR_ARG;
-  a.X = X; a.y = y; a.n = n; a.d = d; a.k = k; a.C = n_chains; a.T = n_transitions; a.L = n_leapfrog;
-  a.eps = step_size; a.eps_chain = step_sizes; a.seed = seed; a.step0 = first_step;
-  a.evaluate_initial = evaluate_initial; a.z = z; a.g = grad_z; a.lp = lp; a.momenta_in = momenta_in;
-  a.log_u_in = log_u_in; a.z_out = z_out; a.lp_out = lp_out; a.acc_out = accepted_out; a.lr_out = log_ratio_out;
-  if (n_transitions == 0 && !evaluate_initial) return BVI_OK;
+  a.X = X; a.y = y; a.n = n; a.d = d; a.k = k;
+  if (a.T == 0 && !a.evaluate_initial) return BVI_OK;
   const int threads = n <= 1024 ? 64 : 256;
   hipStream_t s = (hipStream_t)stream;
-  if (family == BVI_FAMILY_NORMAL_IID) launch<BVI_FAMILY_NORMAL_IID, 1>(bl, a, threads, s);
+  if (family == BVI_FAMILY_NORMAL_IID) launch<BVI_FAMILY_NORMAL_IID, 1>(bl, a, algo, threads, s);
   else if (family == BVI_FAMILY_LINREG) {
-    if (d <= 1) launch<BVI_FAMILY_LINREG, 1>(bl, a, threads, s);
-    else if (d <= 2) launch<BVI_FAMILY_LINREG, 2>(bl, a, threads, s);
-    else if (d <= 4) launch<BVI_FAMILY_LINREG, 4>(bl, a, threads, s);
-    else if (d <= 8) launch<BVI_FAMILY_LINREG, 8>(bl, a, threads, s);
-    else launch<BVI_FAMILY_LINREG, 16>(bl, a, threads, s);
+    if (d <= 1) launch<BVI_FAMILY_LINREG, 1>(bl, a, algo, threads, s);
+    else if (d <= 2) launch<BVI_FAMILY_LINREG, 2>(bl, a, algo, threads, s);
+    else if (d <= 4) launch<BVI_FAMILY_LINREG, 4>(bl, a, algo, threads, s);
+    else if (d <= 8) launch<BVI_FAMILY_LINREG, 8>(bl, a, algo, threads, s);
+    else launch<BVI_FAMILY_LINREG, 16>(bl, a, algo, threads, s);
   } else {
-    if (k <= 2) launch<BVI_FAMILY_GMM1D, 2>(bl, a, threads, s);
-    else if (k <= 4) launch<BVI_FAMILY_GMM1D, 4>(bl, a, threads, s);
-    else launch<BVI_FAMILY_GMM1D, 8>(bl, a, threads, s);
+    if (k <= 2) launch<BVI_FAMILY_GMM1D, 2>(bl, a, algo, threads, s);
+    else if (k <= 4) launch<BVI_FAMILY_GMM1D, 4>(bl, a, algo, threads, s);
+    else launch<BVI_FAMILY_GMM1D, 8>(bl, a, algo, threads, s);
   }
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
+}
+
+}  // namespace
+
+extern "C" int bvi_hmc_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
+                             const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                             const float* step_sizes, int n_leapfrog, int n_transitions, uint64_t seed,
+                             uint64_t first_step, int evaluate_initial, float* z, float* grad_z, float* lp,
+                             const float* momenta_in, const float* log_u_in, float* z_out, float* lp_out,
+                             unsigned char* accepted_out, float* log_ratio_out, void* stream) {
+  if (n_leapfrog < 1) return BVI_ERR_ARG;
+  FusedArgs a = {};
+  a.C = n_chains; a.T = n_transitions; a.L = n_leapfrog;
+  a.eps = step_size; a.eps_chain = step_sizes; a.seed = seed; a.step0 = first_step;
+  a.evaluate_initial = evaluate_initial; a.z = z; a.g = grad_z; a.lp = lp; a.momenta_in = momenta_in;
+  a.log_u_in = log_u_in; a.z_out = z_out; a.lp_out = lp_out; a.acc_out = accepted_out; a.lr_out = log_ratio_out;
+  return run_fused(0, family, X, y, n, d, k, blocks, n_blocks, a, stream);
+}
+
+extern "C" int bvi_nuts_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
+                              const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                              const float* step_sizes, int max_tree_depth, float max_energy_diff,
+                              int n_transitions, uint64_t seed, uint64_t first_step, int evaluate_initial, float* z,
+                              float* grad_z, float* lp, float* z_out, float* lp_out, unsigned char* moved_out,
+                              float* log_accept_out, int* leapfrogs_out, unsigned char* diverged_out,
+                              void* stream) {
+  if (max_tree_depth < 1 || max_tree_depth > kMaxDepth || !(max_energy_diff > 0.f)) return BVI_ERR_ARG;
+  FusedArgs a = {};
+  a.C = n_chains; a.T = n_transitions; a.L = 1;
+  a.eps = step_size; a.eps_chain = step_sizes; a.seed = seed; a.step0 = first_step;
+  a.evaluate_initial = evaluate_initial; a.z = z; a.g = grad_z; a.lp = lp;
+  a.z_out = z_out; a.lp_out = lp_out; a.acc_out = moved_out; a.lr_out = log_accept_out;
+  a.max_depth = max_tree_depth; a.max_energy_diff = max_energy_diff; a.leap_out = leapfrogs_out;
+  a.div_out = diverged_out;
+  return run_fused(1, family, X, y, n, d, k, blocks, n_blocks, a, stream);
 }

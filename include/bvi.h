@@ -216,6 +216,24 @@ int bvi_hmc_fused(int family, const float* X, const float* y, int64_t n, int d, 
                   const float* log_u_in, float* z_out, float* lp_out, unsigned char* accepted_out,
                   float* log_ratio_out, void* stream);
 
+/* The No-U-Turn sampler in the same one-workgroup-per-chain form: n_transitions whole transitions per
+ * launch, each an iterative tree doubling up to max_tree_depth (<= 10) with multinomial sampling inside
+ * subtrees, biased progressive sampling between them, checkpointed U-turn checks and a divergence test
+ * against max_energy_diff; replaces tfp.mcmc.NoUTurnSampler.one_step iterated by tfp.mcmc.sample_chain
+ * (bayes_vi/inference/mcmc/transition_kernels.py:238-246, mcmc.py:160-171; defaults step_size 0.01,
+ * max_tree_depth 5, max_energy_diff 1000 as at transition_kernels.py:148-150).  Arguments as for
+ * bvi_hmc_fused; randomness is Philox only (momenta: stream 0; direction and subtree-accept uniform:
+ * words 0, 1 of block `depth`, stream 2; multinomial uniform of the n-th leapfrog: word 0 of block n,
+ * stream 3).  Per-transition outputs, all optional: z_out [T,C,Pu], lp_out [T,C], moved_out [T,C] (the
+ * sample left the initial point), log_accept_out [T,C] (log of the mean min(1, exp(-dH)) over the
+ * trajectory: what step-size adaptation consumes), leapfrogs_out [T,C], diverged_out [T,C]. */
+int bvi_nuts_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
+                   const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                   const float* step_sizes, int max_tree_depth, float max_energy_diff, int n_transitions,
+                   uint64_t seed, uint64_t first_step, int evaluate_initial, float* z, float* grad_z, float* lp,
+                   float* z_out, float* lp_out, unsigned char* moved_out, float* log_accept_out,
+                   int* leapfrogs_out, unsigned char* diverged_out, void* stream);
+
 /* The generator itself, for tests and for callers that want the same streams: raw Philox4x32-10
  * blocks out[n_chains, n_blocks, 4] for counter (step lo, step hi, chain, block | stream_id << 28)
  * and key (seed lo, seed hi); and the standard normals out[n_chains, n_params] that bvi_hmc_begin

@@ -356,6 +356,71 @@ def test_fused_hmc_through_mcmc_fit_posterior_moments(bvi):
     assert loc.std() == pytest.approx(sl, rel=0.08) and scale.std() == pytest.approx(ss, rel=0.10)
 
 
+def test_fused_nuts_kernel_follows_oracle_transition_by_transition(bvi, gpu_device):
+    """bvi_nuts_fused against oracle/nuts.py, which draws the same Philox numbers: every transition of
+    a 40-transition launch is replayed by the oracle from the device's own previous state and must give
+    the same tree (leapfrog count), the same move decision and the same new position -- unless one of
+    the oracle's comparisons was too close to call in float32 (its `margin`), which is rare."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import FusedNoUTurnSamplerKernel, fused_family
+    from oracle import nuts
+    rng = np.random.default_rng(31)
+    for name, model, ds, spec, z in _fused_cases(bvi, rng):
+        post = bvi.MCMC(model, ds).posterior
+        fam = fused_family(post)
+        z = z.astype(np.float32)[:3]
+        c, pu = z.shape
+        eps = {'normal': 0.2, 'linreg': 0.01, 'gmm1d': 0.04}[name]
+        kern = FusedNoUTurnSamplerKernel(post, fam, step_size=eps, max_tree_depth=4, seed=5)
+        zt = torch.tensor(z, device=gpu_device)
+        st = kern.bootstrap(zt)
+        T = 40
+        zs, zf, stf, tr = kern.many_steps(zt, st, T)
+        zs = zs.cpu().numpy(); lps = tr['target_log_prob'].cpu().numpy()
+        leaps = tr['leapfrogs_taken'].cpu().numpy(); moved = tr['is_accepted'].cpu().numpy()
+        lrs = tr['log_accept_ratio'].cpu().numpy()
+        assert not tr['has_divergence'].any()
+        assert leaps.min() >= 1 and leaps.max() <= 15, name
+        f = lambda q: spec.log_post_unconstrained(q)
+        compared = 0
+        for ch in range(c):
+            prev = z[ch].astype(np.float64)
+            for t in range(T):
+                lp0, g0 = f(prev[None])
+                out = nuts.nuts_step(f, prev, float(lp0[0]), g0[0], chain=ch, seed=5, step=t, step_size=eps,
+                                     max_tree_depth=4)
+                if out['margin'] > 2e-3:
+                    assert out['leapfrogs'] == leaps[t, ch], (name, ch, t)
+                    assert out['moved'] == bool(moved[t, ch]), (name, ch, t)
+                    np.testing.assert_allclose(zs[t, ch], out['z'], rtol=2e-4, atol=2e-4)
+                    assert abs(lrs[t, ch] - out['log_accept_ratio']) < 5e-3
+                    compared += 1
+                prev = zs[t, ch].astype(np.float64)
+        assert compared > 0.6 * c * T, (name, compared)
+
+
+def test_fused_nuts_through_mcmc_fit(bvi):
+    """BASELINE configs[0] through MCMC.fit: the driver selects the fused NUTS kernel; dual averaging runs
+    transition by transition during adaptation, the remaining burn-in and all samples are one launch each."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import FusedNoUTurnSamplerKernel
+    rng = np.random.default_rng(1)
+    y = rng.normal(7, 3, 20).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    cfg = bvi.NoUTurnSampler(stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(num_adaptation_steps=800))
+    mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=cfg)
+    kernel, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
+    assert isinstance(kernel.inner, FusedNoUTurnSamplerKernel)
+    res = mcmc.fit(num_chains=2, num_samples=4000, num_burnin_steps=1000, progress_bar=False, seed=5)
+    loc, scale = (s.cpu().numpy() for s in res.samples)
+    assert loc.shape == (4000, 2) and set(res.trace.keys()) == set(names)
+    ml, sl, ms, ss = exact_normal_moments(y.astype(np.float64))
+    assert loc.mean() == pytest.approx(ml, abs=5 * sl / math.sqrt(8000 / 1.5) + 0.02 * sl)
+    assert scale.mean() == pytest.approx(ms, abs=5 * ss / math.sqrt(8000 / 1.5) + 0.02 * ss)
+    assert loc.std() == pytest.approx(sl, rel=0.08) and scale.std() == pytest.approx(ss, rel=0.10)
+    assert not bool(res.trace['has_divergence'].any())
+    assert 1 <= int(res.trace['leapfrogs_taken'].min()) and int(res.trace['leapfrogs_taken'].max()) <= 31
+    assert 0.6 < float(torch.exp(res.trace['log_accept_ratio']).mean()) < 0.95
+
+
 def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
     """BASELINE configs[3] in miniature: full-covariance mixture, FillScaleTriL-constrained Cholesky
     factors, posterior assembly against the oracle and a short NUTS run."""

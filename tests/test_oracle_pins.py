@@ -266,3 +266,36 @@ def test_philox_known_answers():
     assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
     assert not np.array_equal(philox.normals(7, 3, 4, 8), philox.normals(7, 4, 4, 8))
     np.testing.assert_array_equal(philox.normals(7, 3, 4, 8), philox.normals(7, 3, 4, 8))
+
+
+def test_oracle_nuts_reproduces_exact_posterior_moments():
+    """The oracle's No-U-Turn transition (oracle/nuts.py), iterated on the 20-point Gaussian model of
+    README.md:114-162, must reproduce the exact posterior moments (quadrature of the same log posterior):
+    this is what pins the restated algorithm in the absence of TFP outputs."""
+    import math
+    from oracle import nuts
+    rng = np.random.default_rng(1)
+    y = rng.normal(7, 3, 20)
+    spec = cf.normal_model(y)
+    f = lambda q: spec.log_post_unconstrained(q)
+    z = np.array([7.0, 1.0])
+    lp, g = f(z[None]); lp, g = float(lp[0]), g[0]
+    draws, leaps = [], []
+    for t in range(2500):
+        out = nuts.nuts_step(f, z, lp, g, chain=0, seed=11, step=t, step_size=0.35, max_tree_depth=5)
+        z, lp, g = out['z'], out['lp'], out['g']
+        if t >= 300:
+            draws.append(z.copy()); leaps.append(out['leapfrogs'])
+    draws = np.array(draws)
+    loc, scale = draws[:, 0], np.log1p(np.exp(draws[:, 1]))
+    m, s = y.mean(), y.std(ddof=1)
+    L, S = np.meshgrid(np.linspace(m - 6 * s / math.sqrt(20), m + 6 * s / math.sqrt(20), 241),
+                       np.linspace(s * 0.35, s * 3.0, 401), indexing='ij')
+    lpc, _ = spec.log_post_constrained(np.stack([L.ravel(), S.ravel()], -1))
+    w = np.exp(lpc - lpc.max()).reshape(L.shape); w /= w.sum()
+    ml, ms = (w * L).sum(), (w * S).sum()
+    sl, ss = math.sqrt((w * (L - ml) ** 2).sum()), math.sqrt((w * (S - ms) ** 2).sum())
+    n_eff = len(draws) / 2.0
+    assert abs(loc.mean() - ml) < 5 * sl / math.sqrt(n_eff) and abs(scale.mean() - ms) < 5 * ss / math.sqrt(n_eff)
+    assert abs(loc.std() / sl - 1) < 0.1 and abs(scale.std() / ss - 1) < 0.12
+    assert 1 <= min(leaps) and max(leaps) <= 31 and np.mean(leaps) > 2

@@ -1,0 +1,60 @@
+"""BASELINE configs[4] on one GPU: ELBO gradient steps of mean-field ADVI (and a Hamiltonian-flow surrogate)
+on the 10M x 64 regression with 256 Monte-Carlo samples per step."""
+import collections, os, sys, time
+import numpy as np, pandas as pd, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
+import bayes_vi_amd.distributions as tfd
+from bayes_vi_amd import symbolic
+from bayes_vi_amd.model import Model
+from bayes_vi_amd.inference.vi import VI
+from bayes_vi_amd.inference.vi.surrogate_posteriors import ADVI, NormalizingFlow
+from bayes_vi_amd.inference.vi.flow_bijectors import HamiltonianFlow
+from bayes_vi_amd.inference.vi.vi import Adam
+from bayes_vi_amd.utils.datasets import TensorDataset
+
+n, d, S = int(os.environ.get('ROWS', 10_000_000)), 64, 256
+dev = torch.device('cuda:0')
+g = torch.Generator(device=dev); g.manual_seed(0)
+X = torch.empty(n, d, device=dev)
+for s in range(0, n, 1 << 20):
+    X[s:s + (1 << 20)].normal_(generator=g)
+w = torch.randn(d, generator=g, device=dev)
+y = 0.5 + X @ w + torch.randn(n, generator=g, device=dev)
+priors = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros(d), 10.), scale=tfd.HalfNormal(10.))
+model = Model(priors, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
+ds = TensorDataset(X, y)
+for name, make in (('mean-field ADVI', lambda: ADVI(model, mean_field=True)),
+                   ('Hamiltonian flow (2 layers)', None)):
+    if make is None:
+        try:
+            nd = model.flat_unconstrained_param_event_ndims
+            flow = HamiltonianFlow(nd, step_sizes=torch.nn.Parameter(torch.tensor(0.1)), num_integration_steps=2)
+            sur = NormalizingFlow(model=model, flow_bijector=flow, extra_ndims=nd)
+        except Exception as e:
+            print('skip flow:', repr(e)); continue
+    else:
+        sur = make()
+    vi = VI(model, ds, sur)
+    params = [p for p in vi.surrogate_posterior.parameters() if p.requires_grad]
+    opt = Adam(1e-2).bind(params)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = vi.loss(S)
+        loss.backward()
+        for p in params:
+            if p.grad is not None:
+                p.grad.mul_(torch.clamp(1.0 / (p.grad.norm() + 1e-30), max=1.0))
+        opt.step()
+        return loss
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 20
+    for _ in range(K):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    print('%s: N=%d D=%d S=%d: %.3f ms / ELBO-gradient step, %.1f K sample-gradients/s, loss %.4g'
+          % (name, n, d, S, 1e3 * dt, S / dt / 1e3, float(loss)), flush=True)
