@@ -135,7 +135,12 @@ class FillScaleTriL(Bijector):
         self._isdiag = isd1[None].expand(batch, -1).reshape(-1)
 
     def _to(self, dev):
-        return self._src.to(dev), self._dst.to(dev), self._isdiag.to(dev)
+        # index tensors are uploaded once per device (a per-call upload blocks and cannot be graph-captured)
+        cache = self.__dict__.setdefault('_dev_cache', {})
+        key = str(dev)
+        if key not in cache:
+            cache[key] = (self._src.to(dev), self._dst.to(dev), self._isdiag.to(dev))
+        return cache[key]
 
     def forward(self, x):
         src, dst, isd = self._to(x.device)

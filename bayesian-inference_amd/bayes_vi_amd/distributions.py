@@ -31,6 +31,22 @@ def _t(v, like=None):
         return v  # symbolic expression
 
 
+_DEVICE_COPIES = {}
+
+
+def _on(t, device):
+    """Hyper-parameter tensor `t` on `device`, copied once and cached (a per-call `.to(device)` of a host
+    tensor is a blocking upload: slow in a sampling loop and not allowed under HIP graph capture)."""
+    if t.device == device:
+        return t
+    key = (id(t), str(device))
+    hit = _DEVICE_COPIES.get(key)
+    if hit is None or hit[0] is not t:
+        hit = (t, t.to(device))
+        _DEVICE_COPIES[key] = hit
+    return hit[1]
+
+
 def _is_concrete(*vs):
     return all(isinstance(v, torch.Tensor) for v in vs)
 
@@ -81,18 +97,18 @@ class Normal(Distribution):
         return torch.broadcast_shapes(self.loc.shape, self.scale.shape)
 
     def log_prob(self, x):
-        z = (x - self.loc.to(x.device)) / self.scale.to(x.device)
-        return -0.5 * z * z - 0.5 * LN2PI - torch.log(self.scale.to(x.device))
+        z = (x - _on(self.loc, x.device)) / _on(self.scale, x.device)
+        return -0.5 * z * z - 0.5 * LN2PI - torch.log(_on(self.scale, x.device))
 
     def log_prob_flat(self, x):
-        loc = self.loc.to(x.device).expand(self.batch_shape).reshape(-1) if self.loc.dim() else self.loc.to(x.device)
-        sc = self.scale.to(x.device).expand(self.batch_shape).reshape(-1) if self.scale.dim() else self.scale.to(x.device)
+        loc = _on(self.loc, x.device).expand(self.batch_shape).reshape(-1) if self.loc.dim() else _on(self.loc, x.device)
+        sc = _on(self.scale, x.device).expand(self.batch_shape).reshape(-1) if self.scale.dim() else _on(self.scale, x.device)
         z = (x - loc) / sc
         return (-0.5 * z * z - 0.5 * LN2PI - torch.log(sc)).sum(-1)
 
     def score_flat(self, x):
-        loc = self.loc.to(x.device).expand(self.batch_shape).reshape(-1) if self.loc.dim() else self.loc.to(x.device)
-        sc = self.scale.to(x.device).expand(self.batch_shape).reshape(-1) if self.scale.dim() else self.scale.to(x.device)
+        loc = _on(self.loc, x.device).expand(self.batch_shape).reshape(-1) if self.loc.dim() else _on(self.loc, x.device)
+        sc = _on(self.scale, x.device).expand(self.batch_shape).reshape(-1) if self.scale.dim() else _on(self.scale, x.device)
         return -(x - loc) / (sc * sc)
 
     def sample(self, sample_shape=(), generator=None):
@@ -109,11 +125,11 @@ class HalfNormal(Distribution):
         return self.scale.shape if _is_concrete(self.scale) else torch.Size(())
 
     def _sc(self, x):
-        sc = self.scale.to(x.device)
+        sc = _on(self.scale, x.device)
         return sc.reshape(-1) if sc.dim() else sc
 
     def log_prob(self, x):
-        sc = self.scale.to(x.device)
+        sc = _on(self.scale, x.device)
         lp = 0.5 * math.log(2.0 / math.pi) - torch.log(sc) - 0.5 * (x / sc) ** 2
         return torch.where(x < 0, torch.full_like(lp, -math.inf), lp)
 
@@ -147,7 +163,7 @@ class Dirichlet(Distribution):
         return self.concentration.shape[:-1]
 
     def log_prob(self, x):
-        a = self.concentration.to(x.device)
+        a = _on(self.concentration, x.device)
         norm = torch.lgamma(a.sum(-1)) - torch.lgamma(a).sum(-1)
         return norm + ((a - 1.0) * torch.log(x)).sum(-1)
 
@@ -155,7 +171,7 @@ class Dirichlet(Distribution):
         return self.log_prob(x)
 
     def score_flat(self, x):
-        return (self.concentration.to(x.device) - 1.0) / x
+        return (_on(self.concentration, x.device) - 1.0) / x
 
     def sample(self, sample_shape=(), generator=None):
         a = self.concentration.expand(tuple(sample_shape) + tuple(self.concentration.shape))

@@ -197,6 +197,27 @@ def test_vi_meanfield_advi_and_hnf(bvi):
     assert np.isfinite(l3).all() and l3[-50:].mean() < l3[:20].mean()
 
 
+def test_vi_graph_capture_agrees_with_eager_steps(bvi):
+    """VI.fit replays the whole optimisation step as a captured HIP graph by default; it must optimise
+    the same objective as step-by-step execution: same converged loss and fitted posterior moments."""
+    rng = np.random.default_rng(3)
+    y = rng.normal(7, 3, 100).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    out = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        vi = bvi.VI(model=model, dataset=ds, surrogate_posterior=bvi.ADVI(model, mean_field=True))
+        post, losses = vi.fit(optimizer=bvi.Adam(learning_rate=5e-2), num_steps=1500, sample_size=20,
+                              num_samples_to_approx_marginals=4000, progress_bar=False, capture_graph=mode)
+        assert losses.shape == (1500,) and np.isfinite(losses).all()
+        out[mode] = (losses[-300:].mean(), post)
+    assert out[True][0] == pytest.approx(out[False][0], rel=5e-3)
+    ml, sl, ms, ss = exact_normal_moments(y.astype(np.float64))
+    for mode in (False, True):
+        assert float(out[mode][1]['loc'].mean()) == pytest.approx(ml, abs=0.15)
+        assert float(out[mode][1]['scale'].mean()) == pytest.approx(ms, abs=0.15)
+
+
 def test_device_philox_matches_oracle(gpu_device):
     from bayes_vi_amd import _native
     from oracle import philox
