@@ -71,10 +71,12 @@ def lib():
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_nuts_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, vp, i32, f32, i32, u64, u64, i32,
                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_rwm_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, i32, u64, u64, i32,
+                                    vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]
         l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
         for name in ('bvi_constrain', 'bvi_posterior_assemble', 'bvi_leapfrog_pre', 'bvi_leapfrog_post',
-                     'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_hmc_fused', 'bvi_nuts_fused', 'bvi_philox_uint32', 'bvi_philox_normal'):
+                     'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_hmc_fused', 'bvi_nuts_fused', 'bvi_rwm_fused', 'bvi_philox_uint32', 'bvi_philox_normal'):
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',

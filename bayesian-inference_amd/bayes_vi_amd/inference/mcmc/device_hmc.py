@@ -217,3 +217,53 @@ class FusedNoUTurnSamplerKernel:
     def one_step(self, z, state, generator=None):
         zs, z, state, tr = self.many_steps(z, state, 1, generator)
         return z, state, {k: v[0] for k, v in tr.items()}
+
+
+class FusedRandomWalkMetropolisKernel:
+    """Random-walk Metropolis with whole runs of transitions inside one kernel launch (bvi_rwm_fused);
+    same transition as `samplers.RandomWalkMetropolisKernel` with the default N(0, scale^2) proposal."""
+    trace_names = ('is_accepted',)
+    supports_many_steps = True
+
+    def __init__(self, posterior, family, scale=1.0, seed=0):
+        self.posterior = posterior
+        self.family = family
+        self.blocks = posterior.device_blocks()
+        self.nb = len(self.blocks)
+        self.scale = float(scale)
+        self.seed = int(seed)
+        self.transition = 0
+
+    def _launch(self, z, g, lp, n_transitions, evaluate_initial, seed, outs=None):
+        fam, X, y, n, d, k = self.family
+        ptr = _native._ptr
+        outs = outs if outs is not None else (None,) * 4
+        _native.check(_native.lib().bvi_rwm_fused(
+            fam, ptr(X), ptr(y), n, d, k, self.blocks, self.nb, z.shape[0], self.scale, n_transitions, seed,
+            self.transition, 1 if evaluate_initial else 0, ptr(z), ptr(g), ptr(lp), *[ptr(o) for o in outs],
+            _native._stream()), 'bvi_rwm_fused')
+        self.transition += n_transitions
+
+    def bootstrap(self, z):
+        z = z.contiguous().to(torch.float32)
+        g = torch.empty_like(z)
+        lp = torch.empty(z.shape[0], dtype=torch.float32, device=z.device)
+        self._launch(z, g, lp, 0, True, self.seed)
+        return {'target_log_prob': lp, 'grad': g}
+
+    def many_steps(self, z, state, n, generator=None):
+        z = z.clone().contiguous()
+        lp = state['target_log_prob'].clone()
+        g = state['grad'].clone()
+        c, pu = z.shape
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=z.device)
+        zs, lps, lrs = f(n, c, pu), f(n, c), f(n, c)
+        acc = torch.empty(n, c, dtype=torch.uint8, device=z.device)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        self._launch(z, g, lp, n, False, seed, (zs, lps, acc, lrs))
+        traces = {'is_accepted': acc.to(torch.bool), 'target_log_prob': lps, 'log_accept_ratio': lrs}
+        return zs, z, {'target_log_prob': lp, 'grad': g}, traces
+
+    def one_step(self, z, state, generator=None):
+        zs, z, state, tr = self.many_steps(z, state, 1, generator)
+        return z, state, {k: v[0] for k, v in tr.items()}

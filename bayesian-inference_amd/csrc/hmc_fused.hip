@@ -24,7 +24,8 @@
 // the data-dependent tree depth is ordinary uniform control flow.  Same algorithm, step for step, as
 // the batched host kernel (inference/mcmc/samplers.py::NoUTurnSamplerKernel); random numbers are
 // Philox draws: momenta on stream 0, (direction, subtree-accept) per depth on stream 2, the
-// multinomial uniform per leaf on stream 3.
+// multinomial uniform per leaf on stream 3.  ALGO = 2 is random-walk Metropolis
+// (tfp.mcmc.RandomWalkMetropolis, transition_kernels.py:319-321) with the same streams as HMC.
 #include "bvi_common.h"
 #include "posterior_device.h"
 
@@ -333,6 +334,35 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
         }
       }
     }
+  } else if constexpr (ALGO == 2) {
+    // random-walk Metropolis: z' = z + scale * N(0, I) (scale in a.eps), accept on the log-density ratio
+    for (int t = 0; t < a.T; ++t) {
+      const uint64_t step = a.step0 + (uint64_t)t;
+      float zp = 0.f;
+      if (zl) {
+        float v[4];
+        normal4(draw(a.seed, step, c, lane >> 2, 0), v);
+        zp = fmaf(eps, v[lane & 3], zj);
+      }
+      float lpp, gp;
+      evaluate(zp, lpp, gp);
+      float lr = lpp - lp;
+      if (!isfinite(lr)) lr = -INFINITY;
+      const bool acc = logf(u01(draw(a.seed, step, c, 0, 1).x)) < lr;
+      if (acc) {
+        zj = zp;
+        gj = gp;
+        lp = lpp;
+      }
+      if (wave == 0) {
+        if (a.z_out && zl) a.z_out[((int64_t)t * a.C + c) * Pu + lane] = zj;
+        if (lane == 0) {
+          if (a.lp_out) a.lp_out[(int64_t)t * a.C + c] = lp;
+          if (a.acc_out) a.acc_out[(int64_t)t * a.C + c] = acc ? 1 : 0;
+          if (a.lr_out) a.lr_out[(int64_t)t * a.C + c] = lr;
+        }
+      }
+    }
   } else {
     // sum_j a_j b_j over the chain's elements (lanes beyond Pu hold zeros)
     auto turning = [&](float aq, float ap, float bq, float bp) {
@@ -438,6 +468,7 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
 template <int FAM, int NP>
 void launch(const Blocks& bl, const FusedArgs& a, int algo, int threads, hipStream_t s) {
   if (algo == 0) hipLaunchKernelGGL((hmc_fused_kernel<FAM, NP, 0>), dim3(a.C), dim3(threads), 0, s, bl, a);
+  else if (algo == 2) hipLaunchKernelGGL((hmc_fused_kernel<FAM, NP, 2>), dim3(a.C), dim3(threads), 0, s, bl, a);
   else hipLaunchKernelGGL((hmc_fused_kernel<FAM, NP, 1>), dim3(a.C), dim3(threads), 0, s, bl, a);
 }
 
@@ -497,6 +528,20 @@ extern "C" int bvi_hmc_fused(int family, const float* X, const float* y, int64_t
   a.evaluate_initial = evaluate_initial; a.z = z; a.g = grad_z; a.lp = lp; a.momenta_in = momenta_in;
   a.log_u_in = log_u_in; a.z_out = z_out; a.lp_out = lp_out; a.acc_out = accepted_out; a.lr_out = log_ratio_out;
   return run_fused(0, family, X, y, n, d, k, blocks, n_blocks, a, stream);
+}
+
+extern "C" int bvi_rwm_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
+                             const bvi_param_block* blocks, int n_blocks, int n_chains, float proposal_scale,
+                             int n_transitions, uint64_t seed, uint64_t first_step, int evaluate_initial, float* z,
+                             float* grad_z, float* lp, float* z_out, float* lp_out, unsigned char* accepted_out,
+                             float* log_ratio_out, void* stream) {
+  if (!(proposal_scale > 0.f)) return BVI_ERR_ARG;
+  FusedArgs a = {};
+  a.C = n_chains; a.T = n_transitions; a.L = 1;
+  a.eps = proposal_scale; a.seed = seed; a.step0 = first_step;
+  a.evaluate_initial = evaluate_initial; a.z = z; a.g = grad_z; a.lp = lp;
+  a.z_out = z_out; a.lp_out = lp_out; a.acc_out = accepted_out; a.lr_out = log_ratio_out;
+  return run_fused(2, family, X, y, n, d, k, blocks, n_blocks, a, stream);
 }
 
 extern "C" int bvi_nuts_fused(int family, const float* X, const float* y, int64_t n, int d, int k,

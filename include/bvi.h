@@ -234,6 +234,17 @@ int bvi_nuts_fused(int family, const float* X, const float* y, int64_t n, int d,
                    float* z_out, float* lp_out, unsigned char* moved_out, float* log_accept_out,
                    int* leapfrogs_out, unsigned char* diverged_out, void* stream);
 
+/* Random-walk Metropolis in the same form: z' = z + proposal_scale * N(0, I), accepted with probability
+ * min(1, pi(z') / pi(z)); replaces tfp.mcmc.RandomWalkMetropolis.one_step with its default proposal
+ * (bayes_vi/inference/mcmc/transition_kernels.py:319-321) iterated by tfp.mcmc.sample_chain.  The normal
+ * draws and the accept uniform are those of bvi_hmc_begin / bvi_hmc_end for the same transition number.
+ * grad_z is carried along (in/out) so that the state stays interchangeable with the other samplers. */
+int bvi_rwm_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
+                  const bvi_param_block* blocks, int n_blocks, int n_chains, float proposal_scale,
+                  int n_transitions, uint64_t seed, uint64_t first_step, int evaluate_initial, float* z,
+                  float* grad_z, float* lp, float* z_out, float* lp_out, unsigned char* accepted_out,
+                  float* log_ratio_out, void* stream);
+
 /* The generator itself, for tests and for callers that want the same streams: raw Philox4x32-10
  * blocks out[n_chains, n_blocks, 4] for counter (step lo, step hi, chain, block | stream_id << 28)
  * and key (seed lo, seed hi); and the standard normals out[n_chains, n_params] that bvi_hmc_begin

@@ -377,6 +377,38 @@ def test_fused_hmc_through_mcmc_fit_posterior_moments(bvi):
     assert loc.std() == pytest.approx(sl, rel=0.08) and scale.std() == pytest.approx(ss, rel=0.10)
 
 
+def test_fused_rwm_kernel_follows_oracle(bvi, gpu_device):
+    """bvi_rwm_fused: 25 transitions in one launch against the Metropolis rule applied in float64 to the
+    same Philox proposals and uniforms."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import FusedRandomWalkMetropolisKernel, fused_family
+    from oracle import philox
+    rng = np.random.default_rng(41)
+    for name, model, ds, spec, z in _fused_cases(bvi, rng):
+        post = bvi.MCMC(model, ds).posterior
+        z = z.astype(np.float32)
+        c, pu = z.shape
+        scale = {'normal': 0.3, 'linreg': 0.01, 'gmm1d': 0.03}[name]
+        kern = FusedRandomWalkMetropolisKernel(post, fused_family(post), scale=scale, seed=13)
+        zt = torch.tensor(z, device=gpu_device)
+        zs, zf, stf, tr = kern.many_steps(zt, kern.bootstrap(zt), 25)
+        zs = zs.cpu().numpy(); acc = tr['is_accepted'].cpu().numpy(); lrs = tr['log_accept_ratio'].cpu().numpy()
+        assert 0 < acc.mean() < 1, name
+        prev = z.astype(np.float64)
+        checked = 0
+        for t in range(25):
+            prop = prev + scale * philox.normals(13, t, c, pu).astype(np.float64)
+            lr = spec.log_post_unconstrained(prop)[0] - spec.log_post_unconstrained(prev)[0]
+            lu = philox.log_uniform(13, t, c)
+            safe = np.abs(lu - lr) > 1e-2
+            np.testing.assert_array_equal(acc[t][safe], (lu < lr)[safe])
+            np.testing.assert_allclose(lrs[t], lr, atol=5e-3, rtol=1e-4)
+            want = np.where((lu < lr)[:, None], prop, prev)
+            np.testing.assert_allclose(zs[t][safe], want[safe], rtol=2e-5, atol=2e-5)
+            checked += int(safe.sum())
+            prev = zs[t].astype(np.float64)
+        assert checked > 0.8 * 25 * c
+
+
 def test_fused_nuts_kernel_follows_oracle_transition_by_transition(bvi, gpu_device):
     """bvi_nuts_fused against oracle/nuts.py, which draws the same Philox numbers: every transition of
     a 40-transition launch is replayed by the oracle from the device's own previous state and must give
