@@ -37,64 +37,173 @@ __global__ void philox_normal_kernel(uint64_t seed, uint64_t step, int C, int P,
   }
 }
 
-// ---- posterior assembly ----
+// ---- posterior assembly: one wave per chain, lanes stride over the parameter elements ----
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// log prior of one element and its score
+__device__ __forceinline__ float prior_elem(const bvi_param_block& b, int j, float th, float* score) {
+  if (b.prior == BVI_PRIOR_NORMAL) {
+    const float u = (th - b.a) / b.b;
+    *score = -u / b.b;
+    return -0.5f * u * u - 0.5f * BVI_LN2PI - logf(b.b);
+  }
+  if (b.prior == BVI_PRIOR_HALFNORMAL) {
+    const float u = th / b.a;
+    *score = -u / b.a;
+    return th < 0.f ? -INFINITY : (0.5f * logf(2.f / 3.14159265358979f) - logf(b.a) - 0.5f * u * u);
+  }
+  if (b.prior == BVI_PRIOR_DIRICHLET) {
+    *score = (b.a - 1.f) / th;
+    return (b.a - 1.f) * logf(th) + (j == 0 ? lgammaf(b.a * b.size) - b.size * lgammaf(b.a) : 0.f);
+  }
+  *score = 0.f;
+  return 0.f;
+}
+
+// The work of one chain (one wave).  PRE: the position the constraint is applied to is
+// z + eps (p + eps/2 g), formed on the fly from the old z, p, g (which are updated in place afterwards).
+// ASSEMBLE: also priors, fldj, chain rule (gl gets the prior score added in place, gz is written);
+// HALFSTEP: then p += eps/2 gz.  Every in-place update is made by the lane that owns the element,
+// after all lanes have read what they need of it.
+template <bool PRE, bool ASSEMBLE, bool HALFSTEP>
+__device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __restrict__ z, float* __restrict__ p,
+                           const float* __restrict__ g_old, float* __restrict__ theta, const float* __restrict__ ll,
+                           float* __restrict__ gl, float* __restrict__ lp, float* __restrict__ gz, int c) {
+  const int lane = threadIdx.x & 63;
+  auto zval = [&](int i) -> float {
+    if (PRE) return fmaf(eps, fmaf(0.5f * eps, g_old[i], p[i]), z[i]);
+    return z[i];
+  };
+  float part = 0.f;      // this lane's share of log prior + fldj
+  int oz = 0, ot = 0;
+  for (int i = 0; i < bl.n; ++i) {
+    const bvi_param_block b = bl.b[i];
+    if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED) {
+      float m = 0.f;     // the appended logit is 0
+      for (int j = lane; j < b.size - 1; j += 64) m = fmaxf(m, zval(oz + j));
+      m = wave_max64(m);
+      float sp = 0.f;
+      for (int j = lane; j < b.size - 1; j += 64) sp += expf(zval(oz + j) - m);
+      const float lse = m + logf(expf(-m) + wave_sum64(sp));
+      float inner_p = 0.f;
+      for (int j = lane; j < b.size; j += 64) {
+        const float ly = (j < b.size - 1 ? zval(oz + j) : 0.f) - lse;
+        const float th = expf(ly);
+        theta[ot + j] = th;
+        if (ASSEMBLE) {
+          float sc;
+          part += ly + (j == 0 ? 0.5f * logf((float)b.size) : 0.f) + prior_elem(b, j, th, &sc);
+          if (gl) {
+            const float gt = gl[ot + j] + sc;
+            gl[ot + j] = gt;
+            inner_p += th * gt;
+          }
+        }
+      }
+      if (ASSEMBLE && gl && gz) {
+        const float inner = wave_sum64(inner_p);
+        for (int j = lane; j < b.size - 1; j += 64) {
+          const float th = expf(zval(oz + j) - lse);
+          const float gzj = th * (gl[ot + j] - inner) + 1.f - (float)b.size * th;
+          gz[oz + j] = gzj;
+          if (HALFSTEP) p[oz + j] = fmaf(0.5f * eps, gzj, p[oz + j]);
+        }
+      }
+      if (PRE) {
+        __syncthreads();   // every lane has read the old z, p of this block; now update them in place
+        for (int j = lane; j < b.size - 1; j += 64) {
+          const float pj = fmaf(0.5f * eps, g_old[oz + j], p[oz + j]);
+          p[oz + j] = pj;
+          z[oz + j] = fmaf(eps, pj, z[oz + j]);
+        }
+      }
+    } else {
+      for (int j = lane; j < b.size; j += 64) {
+        const float x = zval(oz + j);
+        float th, fl = 0.f, dth = 1.f, dfl = 0.f;   // theta, fldj share, d theta / dx, d fldj / dx
+        if (b.bijector == BVI_BIJ_SOFTPLUS) {
+          th = softplusf(x); fl = -softplusf(-x); dth = sigmoidf(x); dfl = sigmoidf(-x);
+        } else if (b.bijector == BVI_BIJ_EXP) {
+          th = expf(x); fl = x; dth = th; dfl = 1.f;
+        } else {
+          th = x;
+        }
+        theta[ot + j] = th;
+        if (ASSEMBLE) {
+          float sc;
+          part += fl + prior_elem(b, j, th, &sc);
+          if (gl) {
+            const float gt = gl[ot + j] + sc;
+            gl[ot + j] = gt;
+            if (gz) {
+              const float gzj = fmaf(gt, dth, dfl);
+              gz[oz + j] = gzj;
+              if (HALFSTEP) p[oz + j] = fmaf(0.5f * eps, gzj, p[oz + j]);
+            }
+          }
+        }
+        if (PRE) {         // this lane owns element j: update it in place
+          const float pj = fmaf(0.5f * eps, g_old[oz + j], p[oz + j]);
+          p[oz + j] = pj;
+          z[oz + j] = x;
+        }
+      }
+    }
+    oz += usize_of(b);
+    ot += b.size;
+  }
+  if (ASSEMBLE) {
+    part = wave_sum64(part);
+    if (lane == 0) lp[c] = ll[c] + part;
+  }
+}
+
 // theta = f(z)
-__global__ void constrain_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
-                                 float* __restrict__ theta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  constrain(bl, z + (int64_t)c * Pu, theta + (int64_t)c * P);
+__global__ __launch_bounds__(64) void constrain_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
+                                                       float* __restrict__ theta) {
+  const int c = blockIdx.x;
+  chain_work<false, false, false>(bl, P, Pu, 0.f, const_cast<float*>(z) + (int64_t)c * Pu, nullptr, nullptr,
+                                  theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c);
 }
 
 // lp = ll + log prior(theta) + fldj(z); gz = chain rule of (gl + grad prior); gl is overwritten
-__global__ void assemble_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
-                                float* __restrict__ theta, const float* __restrict__ ll, float* __restrict__ gl,
-                                float* __restrict__ lp, float* __restrict__ gz) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float* zc = z + (int64_t)c * Pu;
-  float* th = theta + (int64_t)c * P;
-  const float fldj = constrain(bl, zc, th);
-  float* g = gl ? gl + (int64_t)c * P : nullptr;
-  const float lpr = log_prior(bl, th, g);
-  lp[c] = ll[c] + lpr + fldj;
-  if (g && gz) chain_rule(bl, zc, th, g, gz + (int64_t)c * Pu);
+__global__ __launch_bounds__(64) void assemble_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
+                                                      float* __restrict__ theta, const float* __restrict__ ll,
+                                                      float* __restrict__ gl, float* __restrict__ lp,
+                                                      float* __restrict__ gz) {
+  const int c = blockIdx.x;
+  chain_work<false, true, false>(bl, P, Pu, 0.f, const_cast<float*>(z) + (int64_t)c * Pu, nullptr, nullptr,
+                                 theta + (int64_t)c * P, ll, gl ? gl + (int64_t)c * P : nullptr, lp,
+                                 gz ? gz + (int64_t)c * Pu : nullptr, c);
 }
 
 // leapfrog "pre": p += eps/2 g; z += eps p; theta = f(z)
-__global__ void leapfrog_pre_kernel(Blocks bl, int C, int P, int Pu, float eps, float* __restrict__ z,
-                                    float* __restrict__ p, const float* __restrict__ g,
-                                    float* __restrict__ theta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float* zc = z + (int64_t)c * Pu;
-  float* pc = p + (int64_t)c * Pu;
-  const float* gc = g + (int64_t)c * Pu;
-  for (int j = 0; j < Pu; ++j) {
-    const float pj = pc[j] + 0.5f * eps * gc[j];
-    pc[j] = pj;
-    zc[j] += eps * pj;
-  }
-  constrain(bl, zc, theta + (int64_t)c * P);
+__global__ __launch_bounds__(64) void leapfrog_pre_kernel(Blocks bl, int C, int P, int Pu, float eps,
+                                                          float* __restrict__ z, float* __restrict__ p,
+                                                          const float* __restrict__ g, float* __restrict__ theta) {
+  const int c = blockIdx.x;
+  chain_work<true, false, false>(bl, P, Pu, eps, z + (int64_t)c * Pu, p + (int64_t)c * Pu, g + (int64_t)c * Pu,
+                                 theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c);
 }
 
 // leapfrog "post": assemble lp, g at the new z, then p += eps/2 g
-__global__ void leapfrog_post_kernel(Blocks bl, int C, int P, int Pu, float eps, const float* __restrict__ z,
-                                     float* __restrict__ p, float* __restrict__ theta,
-                                     const float* __restrict__ ll, float* __restrict__ gl,
-                                     float* __restrict__ lp, float* __restrict__ g) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float* zc = z + (int64_t)c * Pu;
-  float* th = theta + (int64_t)c * P;
-  const float fldj = constrain(bl, zc, th);
-  float* glc = gl + (int64_t)c * P;
-  const float lpr = log_prior(bl, th, glc);
-  lp[c] = ll[c] + lpr + fldj;
-  float* gc = g + (int64_t)c * Pu;
-  chain_rule(bl, zc, th, glc, gc);
-  float* pc = p + (int64_t)c * Pu;
-  for (int j = 0; j < Pu; ++j) pc[j] += 0.5f * eps * gc[j];
+__global__ __launch_bounds__(64) void leapfrog_post_kernel(Blocks bl, int C, int P, int Pu, float eps,
+                                                           const float* __restrict__ z, float* __restrict__ p,
+                                                           float* __restrict__ theta, const float* __restrict__ ll,
+                                                           float* __restrict__ gl, float* __restrict__ lp,
+                                                           float* __restrict__ g) {
+  const int c = blockIdx.x;
+  chain_work<false, true, true>(bl, P, Pu, eps, const_cast<float*>(z) + (int64_t)c * Pu, p + (int64_t)c * Pu,
+                                nullptr, theta + (int64_t)c * P, ll, gl + (int64_t)c * P, lp, g + (int64_t)c * Pu, c);
 }
 
 // HMC begin: save the current state, draw (or copy) momenta, record the initial kinetic energy
@@ -182,7 +291,7 @@ int bvi_constrain(const bvi_param_block* blocks, int n_blocks, int n_chains, con
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
   if (st != BVI_OK) return st;
   if (!z || !theta || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(constrain_kernel, chain_grid(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
+  hipLaunchKernelGGL(constrain_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
                      z, theta);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -195,7 +304,7 @@ int bvi_posterior_assemble(const bvi_param_block* blocks, int n_blocks, int n_ch
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
   if (st != BVI_OK) return st;
   if (!z || !theta || !loglik || !lp || n_chains < 1 || (grad_z && !grad_theta)) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(assemble_kernel, chain_grid(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
+  hipLaunchKernelGGL(assemble_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
                      z, theta, loglik, grad_theta, lp, grad_z);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -208,7 +317,7 @@ int bvi_leapfrog_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, 
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
   if (st != BVI_OK) return st;
   if (!z || !p || !grad_z || !theta || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(leapfrog_pre_kernel, chain_grid(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
+  hipLaunchKernelGGL(leapfrog_pre_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
                      Pu, step_size, z, p, grad_z, theta);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -222,7 +331,7 @@ int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains,
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
   if (st != BVI_OK) return st;
   if (!z || !p || !theta || !loglik || !grad_theta || !lp || !grad_z || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(leapfrog_post_kernel, chain_grid(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
+  hipLaunchKernelGGL(leapfrog_post_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
                      Pu, step_size, z, p, theta, loglik, grad_theta, lp, grad_z);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
