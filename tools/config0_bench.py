@@ -31,7 +31,8 @@ for name, kern in (('NUTS + dual averaging', NoUTurnSampler(stepsize_adaptation_
     print('%s: %d chains x 5000 transitions in %.2f s (%.2f ms/transition)%s; loc %.3f +- %.3f scale %.3f +- %.3f'
           % (name, chains, dt, 1e3 * dt / 5000, extra, loc.mean(), loc.std(), sc.mean(), sc.std()), flush=True)
 
-# the reference's experiment runs (5 chains x 11 000 NUTS steps, N = 100)
+# the reference's experiment runs: 5 chains x 11 000 NUTS steps, N = 100
+# (univariate_gaussian_experiment and linear_regression_experiment, acceptance_and_runtime_summary.txt:6-15)
 rng = np.random.default_rng(3)
 y100 = rng.normal(7, 3, 100).astype(np.float32)
 ds = make_dataset_from_df(pd.DataFrame(dict(y=y100)), target_names=['y'], format_features_as='dict')

@@ -1,4 +1,5 @@
-"""Wall time of the reference's small VI runs: mean-field ADVI and Hamiltonian flows on the
+"""Wall time of the reference's small VI runs (README.md:265-285, 626-643; vi_summary_statistics/final_summary.txt):
+mean-field ADVI and Hamiltonian flows on the
 univariate Gaussian (N = 20, S = 10, 1000 steps; N = 100, S = 50, 10 000 steps)."""
 import collections, os, sys, time
 import numpy as np, pandas as pd, torch
