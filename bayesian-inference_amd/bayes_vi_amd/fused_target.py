@@ -114,11 +114,11 @@ class LinearRegression(FusedLogLikelihood):
         """Packed format the evaluation of `c` chains runs on, or None for the exact-f32 kernels.
         AUTO: many chains on a large shard -> the f16-piece kernel (gradient error at the level of
         the f32 kernel's); BF16X3 / BF16X6 select the bf16-piece kernel explicitly."""
-        if self.d not in (32, 64) or not self.pack:
+        if not self.pack:
             return None
         if self.precision in (_native.PREC_BF16X3, _native.PREC_BF16X6):
-            return _native.PACK_BF16X3
-        if self.precision == _native.PREC_AUTO and c >= 128 and self.n >= 16384:
+            return _native.PACK_BF16X3 if self.d in (32, 64) else None
+        if self.precision == _native.PREC_AUTO and c >= 128 and self.n >= 16384 and self.d <= 64:
             return _native.PACK_F16
         return None
 

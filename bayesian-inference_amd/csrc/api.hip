@@ -55,7 +55,7 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
 
 int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes) {
   if (!out_bytes || n < 0) return BVI_ERR_ARG;
-  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (format == BVI_PACK_F16 ? (d < 1 || d > 64) : (d != 32 && d != 64)) return BVI_ERR_UNSUPPORTED;
   if (format == BVI_PACK_BF16X3) *out_bytes = bvi_linreg_packed_size(n, d);
   else if (format == BVI_PACK_F16) *out_bytes = bvi_linreg_f16_packed_size(n, d);
   else return BVI_ERR_ARG;
@@ -64,7 +64,7 @@ int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes) {
 
 int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes) {
   if (!out_bytes) return BVI_ERR_ARG;
-  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (format == BVI_PACK_F16 ? (d < 1 || d > 64) : (d != 32 && d != 64)) return BVI_ERR_UNSUPPORTED;
   if (format == BVI_PACK_BF16X3) *out_bytes = 0;
   else if (format == BVI_PACK_F16) *out_bytes = bvi_linreg_f16_pack_scratch(d);
   else return BVI_ERR_ARG;
@@ -74,7 +74,7 @@ int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes) {
 int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, int format, void* packed,
                     size_t packed_bytes, void* ws, size_t ws_bytes, void* stream) {
   if (((!X || !y) && n > 0) || n < 0) return BVI_ERR_ARG;
-  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (format == BVI_PACK_F16 ? (d < 1 || d > 64) : (d != 32 && d != 64)) return BVI_ERR_UNSUPPORTED;
   if (format == BVI_PACK_BF16X3) {
     if ((!packed && n > 0) || packed_bytes < bvi_linreg_packed_size(n, d)) return BVI_ERR_WORKSPACE;
     return bvi_launch_linreg_pack(X, y, n, d, packed, (hipStream_t)stream);
@@ -92,7 +92,7 @@ int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, int format
                                 void* stream) {
   if ((!packed && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X6) return BVI_ERR_ARG;
-  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (format == BVI_PACK_F16 ? (d < 1 || d > 64) : (d != 32 && d != 64)) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_linreg(n, n_chains, d)) return BVI_ERR_WORKSPACE;
   if (format == BVI_PACK_BF16X3)
     return bvi_launch_linreg_packed(packed, n, d, theta, n_chains, precision, logp, grad, (float*)ws,

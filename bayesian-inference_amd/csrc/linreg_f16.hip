@@ -29,7 +29,8 @@
 //
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
 //   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
-//   planes [2][n_pad][D] f16: hi(x'), lo(x')           (all zero for padding rows)
+//   planes [2][n_pad][D] f16: hi(x'), lo(x')           (D = 32 or 64 >= the model's feature count; padding
+//                                                       rows and columns are zero)
 //   y      [n_pad] f32                                 (0 for padding rows)
 //
 // Matrix instruction: v_mfma_f32_16x16x32_f16 (wave64).  A[m][k]: lane l holds m = l & 15,
@@ -97,8 +98,10 @@ __device__ __forceinline__ void split_pair(float q0, float q1, unsigned& hi, uns
 
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_kernel(
-    const unsigned char* __restrict__ packed, int64_t n, const float* __restrict__ theta, int C, int ncb, int nrb,
-    float* __restrict__ partials, float* __restrict__ ublk) {
+    const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
+    int nrb, float* __restrict__ partials, float* __restrict__ ublk) {
+  // D: feature count of the packed planes (32 or 64); dr <= D: the model's feature count (columns dr .. D-1
+  // of the planes are zero and take no part)
   constexpr int KS = D / 32;   // k-steps of GEMM1
   constexpr int FT = D / 16;   // feature tiles of GEMM2
   constexpr int SA = 2 * D;    // LDS row stride: no padding, 16-B chunks XOR-swizzled by row (swz below)
@@ -134,14 +137,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int ct = 0; ct < 2; ++ct) {
       const int chain = cbase + 16 * ct + ln;
       const bool cvalid = chain < C;
-      const float* th = theta + (int64_t)(cvalid ? chain : 0) * (D + 2);
+      const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
       float v[KS][8], amax = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int f = 32 * ks + 8 * g + j;
-          v[ks][j] = (cvalid ? -1.f : 0.f) * scaled_weight(th[1 + f], hdr->colscale[f]);
+          v[ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
           amax = fmaxf(amax, fabsf(v[ks][j]));
         }
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));   // the four lane groups hold the chain's D features
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     v += __shfl_xor(v, 32, 64);
     const int chain = cbase + 16 * ct + ln;
     if (chain < C && g == 0) {
-      float* p = partials + ((int64_t)rbi * C + chain) * (D + 2);
+      float* p = partials + ((int64_t)rbi * C + chain) * (dr + 2);
       p[0] = v;
       p[1] = 0.f;   // S1 comes from the packed data sums (finalize)
     }
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = cbase + 16 * ct + 4 * g + i;
-        if (c < C) partials[((int64_t)rbi * C + c) * (D + 2) + 2 + 16 * ft + ln] = G[ct][ft][i];
+        if (c < C && 16 * ft + ln < dr) partials[((int64_t)rbi * C + c) * (dr + 2) + 2 + 16 * ft + ln] = G[ct][ft][i];
       }
   }
 }
@@ -351,8 +354,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // ---- pack: column statistics (two-stage, fixed order) then the split ----
 // stage 1: block b reduces rows b, b + nblk, ... : per column abs-max and sum (double), sum and abs-max of y
 template <int D>
-__global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n,
-                                      float* __restrict__ pmax, double* __restrict__ psum) {
+__global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n, int dr,
+                                    float* __restrict__ pmax, double* __restrict__ psum) {
   // 256 threads = 256 / D row lanes x D columns
   constexpr int RL = 256 / D;
   const int col = threadIdx.x % D, rl = threadIdx.x / D;
@@ -360,7 +363,7 @@ __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __
   float ymax = 0.f;
   double sum = 0.0, ysum = 0.0;
   for (int64_t row = (int64_t)blockIdx.x * RL + rl; row < n; row += (int64_t)gridDim.x * RL) {
-    const float v = X[row * D + col];
+    const float v = col < dr ? X[row * dr + col] : 0.f;
     amax = fmaxf(amax, fabsf(v));
     sum += (double)v;
     if (col == 0) {
@@ -421,7 +424,7 @@ __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* 
 }
 
 template <int D>
-__global__ void f16_pack_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n,
+__global__ void f16_pack_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n, int dr,
                                 int64_t n_pad, unsigned char* __restrict__ packed) {
   constexpr int TPR = D / 8;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
@@ -434,11 +437,14 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
     const int scol = (int)(idx % TPR) * 8;
     const bool ok = row < n;
     float v[8];
-    if (ok) {
+    if (ok && dr == D) {
       const f32x4* p = reinterpret_cast<const f32x4*>(X + row * D + scol);
       const f32x4 a = p[0], b = p[1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    } else if (ok) {      // fewer features than plane columns: rows are not 16-B aligned, the rest is zero
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = scol + j < dr ? X[row * dr + scol + j] : 0.f;
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -498,38 +504,43 @@ constexpr int kStatBlocks = 1024;
 
 }  // namespace
 
+// plane columns for a model with d features
+static int plane_cols(int d) { return d <= 32 ? 32 : 64; }
+
 size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
   const int64_t np = pad_rows(n);
-  return (size_t)(kHeader + np * d * 4 + np * 4);
+  return (size_t)(kHeader + np * plane_cols(d) * 4 + np * 4);
 }
 
 // scratch for the column statistics of the pack step (bytes)
 size_t bvi_linreg_f16_pack_scratch(int d) {
-  return (size_t)kStatBlocks * (d + 1) * sizeof(float) + (size_t)kStatBlocks * (d + 1) * sizeof(double) + 16;
+  const int dp = plane_cols(d);
+  return (size_t)kStatBlocks * (dp + 1) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) + 16;
 }
 
 int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,
-                                 hipStream_t s) {
+                               hipStream_t s) {
   if (((uintptr_t)X & 15) != 0 || ((uintptr_t)packed & 15) != 0 || ((uintptr_t)scratch & 7) != 0)
     return BVI_ERR_ARG;
-  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+  const int dp = plane_cols(d);
   const int64_t np = pad_rows(n);
   double* psum = (double*)scratch;
-  float* pmax = (float*)(psum + (size_t)kStatBlocks * (d + 1));
-  const int64_t total = np * (d / 8);
+  float* pmax = (float*)(psum + (size_t)kStatBlocks * (dp + 1));
+  const int64_t total = np * (dp / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  if (d == 64) {
-    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, pmax, psum);
+  if (dp == 64) {
+    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
     hipLaunchKernelGGL(f16_header_kernel<64>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
                        kStatBlocks, (Header*)packed);
-    hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, np, (unsigned char*)packed);
+    hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
   } else {
-    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, pmax, psum);
+    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
     hipLaunchKernelGGL(f16_header_kernel<32>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
                        kStatBlocks, (Header*)packed);
-    hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, np, (unsigned char*)packed);
+    hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
   }
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -538,7 +549,8 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
 int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
                           float* grad, float* ws, hipStream_t s) {
   if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
-  if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
+  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+  const int dp = plane_cols(d);
   constexpr int cpb = 32 * kWaves;
   const int ncb = bvi_ceil_div(c, cpb);
   int per8 = (kMaxRowBlocks / 8) / ncb;      // one workgroup per CU: ncb * nrb = 256 while ncb <= 32
@@ -548,20 +560,20 @@ int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* the
   const unsigned char* pk = (const unsigned char*)packed;
   // workspace: partials [nrb][c][d+2], then one residual scale per chain block
   float* ublk = ws + (size_t)nrb * c * (d + 2);
-  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * d + 2 * kTileRows * 4);
+  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * dp + 2 * kTileRows * 4);
   static bool lds_ok[2] = {false, false};   // > 64 KB of dynamic LDS has to be allowed once per kernel
-  if (!lds_ok[d == 64]) {
-    const void* fn = d == 64 ? (const void*)&linreg_f16_kernel<64, kWaves> : (const void*)&linreg_f16_kernel<32, kWaves>;
+  if (!lds_ok[dp == 64]) {
+    const void* fn = dp == 64 ? (const void*)&linreg_f16_kernel<64, kWaves> : (const void*)&linreg_f16_kernel<32, kWaves>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_ok[d == 64] = true;
+    lds_ok[dp == 64] = true;
   }
-  if (d == 64)
-    hipLaunchKernelGGL((linreg_f16_kernel<64, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, theta, c, ncb, nrb,
-                       ws, ublk);
+  if (dp == 64)
+    hipLaunchKernelGGL((linreg_f16_kernel<64, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, d, theta, c, ncb,
+                       nrb, ws, ublk);
   else
-    hipLaunchKernelGGL((linreg_f16_kernel<32, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, theta, c, ncb, nrb,
-                       ws, ublk);
+    hipLaunchKernelGGL((linreg_f16_kernel<32, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, d, theta, c, ncb,
+                       nrb, ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * (d + 2);
   hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws,

@@ -132,7 +132,8 @@ def _f16_eval(nat, ws, gpu_device, X, y, th):
 
 @pytest.mark.parametrize('d,c,n', [(64, 1, 1), (64, 128, 64), (64, 256, 1000), (64, 300, 4096 + 17), (32, 128, 5000),
                                    (64, 1024, 20000), (32, 513, 777), (64, 32, 300), (64, 130, 200000),
-                                   (32, 3, 63), (64, 257, 65)])
+                                   (32, 3, 63), (64, 257, 65), (1, 130, 3000), (5, 128, 20000), (17, 200, 4097),
+                                   (33, 129, 1000), (48, 256, 30000), (63, 64, 500)])
 def test_linreg_f16_pieces(nat, ws, gpu_device, d, c, n):
     """The f16-piece kernel (X in 2 pieces, W in 3, residuals in 2; power-of-two range scaling)
     must meet the same 1e-5 bar as the exact-f32 kernels."""
@@ -211,8 +212,10 @@ def test_linreg_f16_pieces_edge_behaviour(nat, ws, gpu_device):
     assert (lp0 == 0).all() and (g0 == 0).all()
     with pytest.raises(nat.BviError):     # this format has one arithmetic; an explicit precision is refused
         nat.linreg_packed_logp_grad(pk, 5000, 64, thd, ws, fmt=nat.PACK_F16, precision=nat.PREC_F32)
-    with pytest.raises(nat.BviError):
-        nat.linreg_pack(Xd[:, :16].contiguous(), yd, fmt=nat.PACK_F16)
+    with pytest.raises(nat.BviError):     # more than 64 features: not covered by the packed formats
+        nat.linreg_pack(torch.zeros(10, 65, device=gpu_device), torch.zeros(10, device=gpu_device), fmt=nat.PACK_F16)
+    with pytest.raises(nat.BviError):     # the bf16 format takes 32 or 64 features only
+        nat.linreg_pack(Xd[:, :16].contiguous(), yd, fmt=nat.PACK_BF16X3)
 
 
 def test_linear_regression_auto_runs_f16_pieces(nat, ws, gpu_device):
