@@ -94,13 +94,27 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
                              % (args.gpus, args.gpus))
         args.gpus = world
-    device = torch.device('cuda', local_rank)
+    # BVI_BENCH_REHEARSAL=1: exercise the multi-rank code path on a box with fewer GPUs than ranks (ranks
+    # share devices, collectives go through gloo); the numbers of such a run mean nothing
+    rehearsal = os.environ.get('BVI_BENCH_REHEARSAL') == '1'
+    device = torch.device('cuda', local_rank % torch.cuda.device_count() if rehearsal else local_rank)
     torch.cuda.set_device(device)
     group = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
         group = dist.group.WORLD
+
+    def all_reduce(t, op):
+        if rehearsal:                      # gloo moves host memory only
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=group)
 
     from bayes_vi_amd import _native, distributions as tfd, bijectors as tfb
     from bayes_vi_amd.fused_target import LinearRegression, Posterior
@@ -142,7 +156,7 @@ def main():
         if timed:
             e1.record(); kernel_events.append((e0, e1))
         if lik.sharded:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            all_reduce(buf, dist.ReduceOp.SUM)
 
     st = _native._stream()
     _native.check(lib.bvi_constrain(blocks, nb, c, ptr(z), ptr(theta), st), 'bvi_constrain')
@@ -173,7 +187,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(lp).all().item())
 
