@@ -25,6 +25,7 @@
 // z in the other orientation (rows in registers, dims on lanes) -- the same MFMAs with the
 // operands swapped -- where the accumulator registers are, lane for lane, BOTH operands of
 // S2 += (rho z)^T z, and S0/S1 are register sums.
+#include <stdlib.h>
 #include "bvi_common.h"
 
 namespace {
@@ -33,8 +34,12 @@ constexpr int DP = 32;        // padded dimension
 constexpr int LS = 34;        // LDS row stride in floats: conflict-free ds_read_b32 operand reads
 constexpr int TR = 16;        // rows per tile
 
-__global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, int D, float* __restrict__ Ainv,
-                                float* __restrict__ bvec, float* __restrict__ cst) {
+__global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, int D,
+                                const float* __restrict__ center, float* __restrict__ Ainv,
+                                float* __restrict__ bvec, float* __restrict__ blo, float* __restrict__ cst) {
+  // blo: optional low part of b (b = bvec + blo to ~2^-48): b is common to all rows of a component, so its
+  // rounding error would add up coherently over the rows
+  // center: optional per-column shift the streaming kernel applies to the data (b = A (mu - center))
   // one block of DP threads per (chain, component)
   const int c = blockIdx.x / K, k = blockIdx.x % K, j = threadIdx.x;
   const int P = K + K * D + K * D * D;
@@ -56,8 +61,11 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
   for (int i = 0; i < DP; ++i) Ao[i * DP + j] = (float)A[i][j];
   double b = 0.0;
   if (j < D)
-    for (int m = 0; m < D; ++m) b += A[j][m] * (double)mu[m];
+    // with the A that the streaming kernel uses (rounded to f32): then u = A_f32 (y - mu) exactly, and the
+    // rounding of A multiplies the zero-mean (y - mu) instead of the common offset (mu - center)
+    for (int m = 0; m < D; ++m) b += (double)(float)A[j][m] * ((double)mu[m] - (center ? (double)center[m] : 0.0));
   bvec[((int64_t)c * K + k) * DP + j] = (float)b;
+  if (blo) blo[((int64_t)c * K + k) * DP + j] = (float)(b - (double)(float)b);
   if (j == 0) {
     double wsum = 0.0, ld = 0.0;
     for (int m = 0; m < K; ++m) wsum += (double)th[m];
@@ -221,6 +229,346 @@ __global__ __launch_bounds__(256) void fullcov_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same sums on the f16 matrix cores (v_mfma_f32_16x16x32_f16), operands split into f16 pieces
+// as in linreg_f16.hip: the data in 2 pieces (error <= 1 f32 ulp, independent from row to row), the
+// whitening matrices A_k in 3 (exact: an error in a parameter is common to all rows and would grow
+// with n), products yh.a1, yl.a1, yh.a2, yh.a3.  Range normalisation by exact powers of two:
+//   y'_id = (y_id - m_d) s_d   (m_d: column mean, s_d = 2^(13 - floor(log2 max_i |y_id - m_d|)); both from a
+//                               statistics pass over Y per call; centring also removes the cancellation
+//                               between A y and A mu for data far from the origin)
+//   A''_k = A_k diag(1/s) t_k, t_k = 2^(13 - floor(log2 max |A_k diag(1/s)|))   (per chain and component)
+// so z' = A'' y' = t_k A_k (y - m) and u = z' / t_k - A_k (mu_k - m).
+// S2_k = sum_i rho_ik u u^T is accumulated as W^T W with w = sqrt(rho) u = exp((a - lse)/2) u split into 2
+// f16 pieces (wh.wh, wl.wh, wh.wl): the accumulator registers of GEMM1 (rows in registers, dims on
+// lanes) are, lane for lane, both the A and the B operand of that product for two 16-row tiles side by
+// side, so S2 needs no LDS traffic at all; S0, S1 are register sums.
+//
+// Workgroup = one chain x a strided set of 64-row tiles, 8 waves, wave w owns components w, w + 8.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int FT = 64;        // rows per tile of the f16 kernel
+constexpr int FW = 8;         // waves per workgroup
+
+__device__ __forceinline__ float fc_pow2_scale(float amax) {
+  if (!(amax > 0.f) || !isfinite(amax)) return 1.f;
+  return ldexpf(1.f, min(max(13 - ilogbf(amax), -126), 126));
+}
+
+__device__ __forceinline__ void fc_split_pair(float q0, float q1, unsigned& hi, unsigned& lo) {
+  asm volatile(
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(q0), "v"(q1));
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
+// column statistics of Y, stage 1: block b reduces rows b, b + nblk, ...: sum (double), min, max per column
+__global__ void fullcov_colstats(const float* __restrict__ Y, int64_t n, int D, double* __restrict__ psum,
+                                 float* __restrict__ pmin, float* __restrict__ pmax) {
+  // 256 threads = 8 row lanes x 32 columns
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  double sum = 0.0;
+  float mn = INFINITY, mx = -INFINITY;
+  if (col < D)
+    for (int64_t row = (int64_t)blockIdx.x * 8 + rl; row < n; row += (int64_t)gridDim.x * 8) {
+      const float v = Y[row * D + col];
+      sum += (double)v;
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+  __shared__ double ssum[256];
+  __shared__ float smn[256], smx[256];
+  ssum[threadIdx.x] = sum; smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
+  __syncthreads();
+  if (rl == 0) {
+    for (int q = 1; q < 8; ++q) {
+      sum += ssum[q * 32 + col];
+      mn = fminf(mn, smn[q * 32 + col]);
+      mx = fmaxf(mx, smx[q * 32 + col]);
+    }
+    psum[blockIdx.x * DP + col] = sum;
+    pmin[blockIdx.x * DP + col] = mn;
+    pmax[blockIdx.x * DP + col] = mx;
+  }
+}
+
+// stage 2: center[d] = mean, cscale[d] = power-of-two scale of max |y - mean| (0 for a constant / unused column)
+__global__ void fullcov_colstats_final(const double* __restrict__ psum, const float* __restrict__ pmin,
+                                       const float* __restrict__ pmax, int nblk, int64_t n, int D,
+                                       float* __restrict__ center, float* __restrict__ cscale) {
+  const int col = threadIdx.x;
+  if (col >= DP) return;
+  double sum = 0.0;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int b = 0; b < nblk; ++b) {
+    sum += psum[b * DP + col];
+    mn = fminf(mn, pmin[b * DP + col]);
+    mx = fmaxf(mx, pmax[b * DP + col]);
+  }
+  float m = 0.f, sc = 0.f;
+  if (col < D && n > 0) {
+    m = (float)(sum / (double)n);
+    if (!isfinite(m)) m = 0.f;
+    const float amax = fmaxf(mx - m, m - mn);
+    sc = amax > 0.f ? fc_pow2_scale(amax) : 0.f;
+  }
+  center[col] = m;
+  cscale[col] = sc;
+}
+
+template <int KQ>  // components per wave (K <= FW * KQ)
+__global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2))) void fullcov_f16_kernel(
+    const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
+    const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
+    const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials) {
+  // LDS: two f16 images of the tile (hi, lo), 64-B rows with the 16-B chunks XOR-swizzled by row so that the
+  // A-operand ds_read_b128 (16 rows x two neighbouring chunks per lane group) is conflict-free; double buffered
+  __shared__ __attribute__((aligned(16))) unsigned char ybuf[2][2][FT * 64];
+  __shared__ float al[FW * KQ][FT];     // a_ik of the tile
+  __shared__ float ls[FT];              // log-sum-exp per row (+inf for rows past the end)
+  __shared__ float lpw[FT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, g = lane >> 4;
+  const int c = blockIdx.y;
+  auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };
+
+  // A''_k as B operand of GEMM1 (k = input dim, n = output dim): lane holds output dim 16 nt + ln, input dims
+  // 8 g .. 8 g + 7, in three f16 pieces; per component also 1 / t_k, b_k for the lane's output dims, the constant
+  f16x8 a1[KQ][2], a2[KQ][2], a3[KQ][2];
+  float inv_t[KQ], bq[KQ][2], bl[KQ][2], cq[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = wave + FW * q;
+    const bool kv = k < K;
+    const float* Ak = Ainv + ((int64_t)c * K + (kv ? k : 0)) * DP * DP;
+    float v[2][8], amax = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = 8 * g + j;
+        const float s = cscale[d];
+        v[nt][j] = (kv && s > 0.f) ? Ak[(16 * nt + ln) * DP + d] / s : 0.f;
+        amax = fmaxf(amax, fabsf(v[nt][j]));
+      }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    const float t = fc_pow2_scale(amax);
+    inv_t[q] = 1.f / t;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = v[nt][j] * t;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        a1[q][nt][j] = hi;
+        a2[q][nt][j] = lo;
+        a3[q][nt][j] = (_Float16)((x - (float)hi) - (float)lo);
+      }
+      bq[q][nt] = kv ? bvec[((int64_t)c * K + k) * DP + 16 * nt + ln] : 0.f;
+      bl[q][nt] = kv ? blo[((int64_t)c * K + k) * DP + 16 * nt + ln] : 0.f;
+    }
+    cq[q] = kv ? cst[c * K + k] : -INFINITY;
+  }
+
+  f32x4 S2[KQ][2][2];
+  float S1[KQ][2], S0[KQ];
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    S0[q] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      S1[q][a] = 0.f;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) S2[q][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float logp_acc = 0.f;
+
+  // staging: thread -> (row = tid / 8, columns 4 (tid % 8) .. + 3)
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  float cm[4], cs[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { cm[e] = center[sc4 + e]; cs[e] = cscale[sc4 + e]; }
+  const bool vec_ok = D == DP && (((uintptr_t)Y & 15) == 0);
+  float yraw[4];
+  auto gload = [&](int64_t tile) {
+    const int64_t gr = tile * FT + srow;
+    if (vec_ok && gr < n) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(Y + gr * DP + sc4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) yraw[e] = t4[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) yraw[e] = (gr < n && sc4 + e < D) ? Y[gr * D + sc4 + e] : cm[e];
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned hi[2], lo[2];
+    float q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = (yraw[e] - cm[e]) * cs[e];
+    fc_split_pair(q[0], q[1], hi[0], lo[0]);
+    fc_split_pair(q[2], q[3], hi[1], lo[1]);
+    // 8-B piece (tid & 1) of 16-B chunk (tid & 7) >> 1 of the row
+    const int off = srow * 64 + ((((tid & 7) >> 1) ^ swz(srow)) << 4) + 8 * (tid & 1);
+    *reinterpret_cast<uint2*>(&ybuf[buf][0][off]) = make_uint2(hi[0], hi[1]);
+    *reinterpret_cast<uint2*>(&ybuf[buf][1][off]) = make_uint2(lo[0], lo[1]);
+  };
+
+  const int64_t ntiles = (n + FT - 1) / FT;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) {
+    gload(tile);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+    const unsigned char* yh = ybuf[buf][0];
+    const unsigned char* yl = ybuf[buf][1];
+    // ---- GEMM1: u = A (y - mu) for the wave's components, rows 4 g + i of each 16-row tile in registers ----
+    f32x4 u[KQ][4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int off = (16 * rt + ln) * 64 + ((g ^ swz(16 * rt + ln)) << 4);
+      const f16x8 fh = *reinterpret_cast<const f16x8*>(yh + off);
+      const f16x8 fl = *reinterpret_cast<const f16x8*>(yl + off);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        f32x4 nrm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a1[q][nt], z, 0, 0, 0);
+          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, a1[q][nt], z, 0, 0, 0);
+          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a2[q][nt], z, 0, 0, 0);
+          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a3[q][nt], z, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float uu = fmaf(z[i], inv_t[q], -bq[q][nt]) - bl[q][nt];
+            u[q][rt][nt][i] = uu;
+            nrm[i] = fmaf(uu, uu, nrm[i]);
+          }
+        }
+        // |u|^2 of row 16 rt + 4 g + i: sum over the 16 lanes that hold its output dims
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nrm[i] = row16_sum(nrm[i]);
+        if (ln == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) al[wave + FW * q][16 * rt + 4 * g + i] = cq[q] - 0.5f * nrm[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < FT) {
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, al[k][tid]);
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s += __expf(al[k][tid] - m);
+      const float lse = m + __logf(s);
+      const bool valid = tile * FT + tid < n;
+      if (valid) logp_acc += lse;
+      ls[tid] = valid ? lse : INFINITY;
+    }
+    __syncthreads();
+    // ---- responsibilities and raw sums: w = sqrt(rho) u in two f16 pieces is both operand of S2 += W^T W ----
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int k = wave + FW * q;
+      if (k < K) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {        // 32-row pairs: k index j <-> row 32 m + 16 (j >> 2) + 4 g + (j & 3)
+          float sr[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int row = 32 * m + 16 * (j >> 2) + 4 * g + (j & 3);
+            sr[j] = __expf(0.5f * (al[k][row] - ls[row]));
+            S0[q] = fmaf(sr[j], sr[j], S0[q]);
+          }
+          f16x8 wh[2], wl[2];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              float w0 = sr[j] * u[q][2 * m + (j >> 2)][nt][j & 3];
+              float w1 = sr[j + 1] * u[q][2 * m + (j >> 2)][nt][(j & 3) + 1];
+              S1[q][nt] = fmaf(sr[j], w0, S1[q][nt]);
+              S1[q][nt] = fmaf(sr[j + 1], w1, S1[q][nt]);
+              w0 = fminf(fmaxf(w0, -60000.f), 60000.f);      // keep the f16 pieces finite for absurd parameters
+              w1 = fminf(fmaxf(w1, -60000.f), 60000.f);
+              fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            wh[nt] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+            wl[nt] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              S2[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], wh[b], S2[q][a][b], 0, 0, 0);
+              S2[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[a], wh[b], S2[q][a][b], 0, 0, 0);
+              S2[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], wl[b], S2[q][a][b], 0, 0, 0);
+            }
+        }
+      }
+    }
+    if (tile + gridDim.x < ntiles) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- partials of this (row block, chain): [K][1 + DP + DP*DP] then the log-prob ----
+  // S2 accumulator: lane holds rows (first index) 16 a + 4 g + i, column 16 b + ln
+  constexpr int Q = 1 + DP + DP * DP;
+  float* out = partials + ((int64_t)blockIdx.x * C + c) * ((int64_t)K * Q + 1);
+#pragma unroll
+  for (int q = 0; q < KQ; ++q) {
+    const int k = wave + FW * q;
+    if (k < K) {
+      // S0: every lane of a 16-lane row holds the same rows; take one lane per row, add the 4 groups
+      float s0 = S0[q];
+      s0 += __shfl_xor(s0, 16, 64);
+      s0 += __shfl_xor(s0, 32, 64);
+      if (lane == 0) out[(int64_t)k * Q] = s0;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float s1 = S1[q][nt];
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (g == 0) out[(int64_t)k * Q + 1 + 16 * nt + ln] = s1;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            out[(int64_t)k * Q + 1 + DP + (16 * nt + 4 * g + i) * DP + 16 * b + ln] = S2[q][nt][b][i];
+      }
+    }
+  }
+  if (tid < FT) lpw[tid] = logp_acc;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < FT; ++i) s += lpw[i];
+    out[(int64_t)K * Q] = s;
+  }
+}
+
 // one block of DP threads per (chain, component); thread j owns column j / entry j
 __global__ void fullcov_finalize(const float* __restrict__ partials, int nb, int64_t n, int D, int K,
                                  const float* __restrict__ theta, const float* __restrict__ Ainv, int C,
@@ -284,26 +632,42 @@ int fullcov_blocks(int64_t n, int c) {
 
 }  // namespace
 
+constexpr int kStatBlocks = 256;
+// floats of workspace in front of everything else: column statistics of Y (doubles first: 8-B aligned)
+constexpr size_t kStatFloats = 2 * (size_t)kStatBlocks * DP + 2 * (size_t)kStatBlocks * DP + 2 * DP;
+
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
   (void)d;
-  const size_t prep = (size_t)c * k * (DP * DP + DP + 1);
+  const size_t prep = (size_t)c * k * (DP * DP + 2 * DP + 1);
   const size_t part = (size_t)fullcov_blocks(n, c) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
-  return (prep + part) * sizeof(float);
+  return (kStatFloats + prep + part) * sizeof(float);
 }
 
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
                            float* grad, float* ws, hipStream_t s) {
   if (d < 1 || d > DP || k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
-  float* Ainv = ws;
+  if (((uintptr_t)ws & 7) != 0) return BVI_ERR_ARG;
+  double* psum = (double*)ws;
+  float* pmin = ws + 2 * (size_t)kStatBlocks * DP;
+  float* pmax = pmin + (size_t)kStatBlocks * DP;
+  float* center = pmax + (size_t)kStatBlocks * DP;
+  float* cscale = center + DP;
+  float* Ainv = ws + kStatFloats;
   float* bvec = Ainv + (size_t)c * k * DP * DP;
-  float* cst = bvec + (size_t)c * k * DP;
+  float* blo = bvec + (size_t)c * k * DP;
+  float* cst = blo + (size_t)c * k * DP;
   float* partials = cst + (size_t)c * k;
-  hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, Ainv, bvec, cst);
-  BVI_HIP_CHECK_LAUNCH();
+  // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
+  // f16-piece kernel is validated against
+  static const bool use_f32 = getenv("BVI_FULLCOV_F32") && atoi(getenv("BVI_FULLCOV_F32")) != 0;
   const int nb = fullcov_blocks(n, c);
-  const int kq = bvi_ceil_div(k, 4);
-  const size_t lds = ((size_t)k * DP * LS + (size_t)k * DP + TR * LS + 4 * kq * TR + TR + 4 * kq) * sizeof(float);
   dim3 grid(nb, c);
+  if (use_f32) {
+    hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)nullptr, Ainv,
+                       bvec, (float*)nullptr, cst);
+    BVI_HIP_CHECK_LAUNCH();
+    const int kq = bvi_ceil_div(k, 4);
+    const size_t lds = ((size_t)k * DP * LS + (size_t)k * DP + TR * LS + 4 * kq * TR + TR + 4 * kq) * sizeof(float);
 #define BVI_FC_CASE(KQ)                                                                                      \
   case KQ: {                                                                                                 \
     hipError_t e = hipFuncSetAttribute((const void*)fullcov_kernel<KQ>,                                      \
@@ -311,13 +675,29 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     if (e != hipSuccess) return (int)e;                                                                      \
     hipLaunchKernelGGL(fullcov_kernel<KQ>, grid, dim3(256), lds, s, Y, n, d, k, Ainv, bvec, cst, c, partials); \
   } break;
-  switch (kq) {
-    BVI_FC_CASE(1)
-    BVI_FC_CASE(2)
-    BVI_FC_CASE(3)
-    BVI_FC_CASE(4)
-  }
+    switch (kq) {
+      BVI_FC_CASE(1)
+      BVI_FC_CASE(2)
+      BVI_FC_CASE(3)
+      BVI_FC_CASE(4)
+    }
 #undef BVI_FC_CASE
+  } else {
+    hipLaunchKernelGGL(fullcov_colstats, dim3(kStatBlocks), dim3(256), 0, s, Y, n, d, psum, pmin, pmax);
+    hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(64), 0, s, (const double*)psum, (const float*)pmin,
+                       (const float*)pmax, kStatBlocks, n, d, center, cscale);
+    hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
+                       bvec, blo, cst);
+    BVI_HIP_CHECK_LAUNCH();
+    if (k <= FW)
+      hipLaunchKernelGGL(fullcov_f16_kernel<1>, grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,
+                         (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, c,
+                         partials);
+    else
+      hipLaunchKernelGGL(fullcov_f16_kernel<2>, grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,
+                         (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, c,
+                         partials);
+  }
   BVI_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(DP), 0, s, (const float*)partials, nb, n, d, k, theta,
                      (const float*)Ainv, c, logp, grad);

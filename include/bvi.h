@@ -149,7 +149,9 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
 /* Full-covariance Gaussian mixture: Y[n,d] row-major,
  * theta[C, k + k*d + k*d*d] = (weights_k, locs[k][d], scale_tril[k][d][d] row-major, entries above the
  * diagonal ignored) -> logp[C], grad[C, same layout] (gradient of scale_tril is lower triangular).
- * d <= 32, k <= 16; exact f32 on the matrix cores.  Replaces the likelihood node
+ * d <= 32, k <= 16; f16-piece arithmetic on the matrix cores (data in 2 pieces, centred and range-normalised
+ * per column by a statistics pass per call; whitening matrices in 3 pieces: exact), f32 accumulation.
+ * Replaces the likelihood node
  * MixtureSameFamily(Categorical(probs), MultivariateNormalTriL(locs, scale_tril)) of
  * exploratory_experiments/multivariate-gaussian-mixture-density-estimation-test.ipynb cell 7. */
 int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
