@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // A''_k as B operand of GEMM1 (k = input dim, n = output dim): lane holds output dim 16 nt + ln, input dims
   // 8 g .. 8 g + 7, in three f16 pieces; per component also 1 / t_k, b_k for the lane's output dims, the constant
   f16x8 a1[KQ][2], a2[KQ][2], a3[KQ][2];
-  float inv_t[KQ], bq[KQ][2], bl[KQ][2], cq[KQ];
+  float inv_t[KQ], zb[KQ][2], bl[KQ][2], cq[KQ];   // zb = -t b_hi (exact: t is a power of two)
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     const int k = wave + FW * q;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         a2[q][nt][j] = lo;
         a3[q][nt][j] = (_Float16)((x - (float)hi) - (float)lo);
       }
-      bq[q][nt] = kv ? bvec[((int64_t)c * K + k) * DP + 16 * nt + ln] : 0.f;
+      zb[q][nt] = kv ? -t * bvec[((int64_t)c * K + k) * DP + 16 * nt + ln] : 0.f;
       bl[q][nt] = kv ? blo[((int64_t)c * K + k) * DP + 16 * nt + ln] : 0.f;
     }
     cq[q] = kv ? cst[c * K + k] : -INFINITY;
@@ -452,14 +452,14 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         f32x4 nrm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          f32x4 z = {zb[q][nt], zb[q][nt], zb[q][nt], zb[q][nt]};    // accumulate on top of -t b_hi
           z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a1[q][nt], z, 0, 0, 0);
           z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, a1[q][nt], z, 0, 0, 0);
           z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a2[q][nt], z, 0, 0, 0);
           z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a3[q][nt], z, 0, 0, 0);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float uu = fmaf(z[i], inv_t[q], -bq[q][nt]) - bl[q][nt];
+            const float uu = fmaf(z[i], inv_t[q], -bl[q][nt]);
             u[q][rt][nt][i] = uu;
             nrm[i] = fmaf(uu, uu, nrm[i]);
           }
@@ -496,7 +496,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int row = 32 * m + 16 * (j >> 2) + 4 * g + (j & 3);
-            sr[j] = __expf(0.5f * (al[k][row] - ls[row]));
+            // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
+            // the gradient sums instead of turning them into NaN; its log-density is already counted
+            const float aik = al[k][row];
+            sr[j] = (aik > cq[q] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (aik - ls[row]));
             S0[q] = fmaf(sr[j], sr[j], S0[q]);
           }
           f16x8 wh[2], wl[2];
@@ -505,12 +508,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             unsigned hw[4], lw[4];
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-              float w0 = sr[j] * u[q][2 * m + (j >> 2)][nt][j & 3];
-              float w1 = sr[j + 1] * u[q][2 * m + (j >> 2)][nt][(j & 3) + 1];
+              const float w0 = sr[j] * u[q][2 * m + (j >> 2)][nt][j & 3];
+              const float w1 = sr[j + 1] * u[q][2 * m + (j >> 2)][nt][(j & 3) + 1];
               S1[q][nt] = fmaf(sr[j], w0, S1[q][nt]);
               S1[q][nt] = fmaf(sr[j + 1], w1, S1[q][nt]);
-              w0 = fminf(fmaxf(w0, -60000.f), 60000.f);      // keep the f16 pieces finite for absurd parameters
-              w1 = fminf(fmaxf(w1, -60000.f), 60000.f);
               fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
             }
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -1,16 +1,17 @@
 #!/bin/bash
-# MFMA utilisation / clock counters for the headline regression kernel (one PMC pass, SQ + GRBM blocks only).
+# MFMA utilisation / clock counters for one kernel (one PMC pass, SQ + GRBM blocks only).  Defaults: the headline
+# regression kernel under tools/kbench.py; PMC_PROG='tools/fullcov_bench.py' PMC_KERNEL=fullcov_f16_kernel for another.
 set -e -o pipefail
 OUT=$PWD/gpurun_out/pmc_kernel
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p" -o p -- python3 tools/kbench.py --f16 --reps 3 "$@" > "$OUT/log.txt" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p" -o p -- python3 ${PMC_PROG:-tools/kbench.py --f16 --reps 3} > "$OUT/log.txt" 2>&1
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 f = glob.glob(sys.argv[1] + '/p/**/*counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    if 'linreg_f16_kernel' in r['Kernel_Name']:
+    if os.environ.get('PMC_KERNEL', 'linreg_f16_kernel') in r['Kernel_Name']:
         acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 import json
 out = {}
