@@ -35,9 +35,13 @@ class ShardedLogLikelihood:
     it with ONE all-reduce per evaluation (RCCL on GPUs, gloo in CPU tests).  Chains are
     replicated: every rank evaluates the same theta and ends up with the same totals.
     `None` = single shard.  Subclasses implement `_call` (the local partial sums).
+    `fixed_order_reduction = True` replaces the all-reduce by an all-gather of the partials and a
+    local sum in rank order: the totals then do not depend on the collective's algorithm (bitwise
+    reproducible across library versions and topologies) at the price of world_size x the bytes.
     """
     family = None
     n_params = None
+    fixed_order_reduction = False
 
     def __init__(self, device, group=None):
         self.device = torch.device(device)
@@ -57,7 +61,16 @@ class ShardedLogLikelihood:
         grad = buf[c:].view(c, self.n_params) if want_grad else None
         self._call(theta, logp, grad)
         if self.sharded:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if self.fixed_order_reduction:
+                world = dist.get_world_size(self.group)
+                parts = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device)
+                dist.all_gather_into_tensor(parts, buf, group=self.group)
+                total = parts[:buf.numel()].clone()
+                for r in range(1, world):           # rank order, the same on every rank
+                    total += parts[r * buf.numel():(r + 1) * buf.numel()]
+                buf.copy_(total)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return logp, grad
 
 

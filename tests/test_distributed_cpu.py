@@ -57,6 +57,14 @@ def _worker(rank, world, port, out):
     assert post.likelihood.sharded
     lp, g = post.unconstrained_log_prob_and_grad(z)
     lpv, _ = post.unconstrained_log_prob_and_grad(z, want_grad=False)
+    # the fixed-order variant (all-gather + sum in rank order) gives the same totals on every rank
+    post.likelihood.fixed_order_reduction = True
+    lpf, gf = post.unconstrained_log_prob_and_grad(z)
+    post.likelihood.fixed_order_reduction = False
+    both = [torch.empty_like(gf) for _ in range(world)]
+    dist.all_gather(both, gf)
+    assert all(torch.equal(both[0], t) for t in both)
+    assert torch.allclose(lpf, lp, rtol=1e-6) and torch.allclose(gf, g, rtol=1e-5, atol=1e-4)
     # a few HMC steps with the same seed on every rank: chains stay replicated bit for bit
     k = samplers.HamiltonianMonteCarloKernel(post.unconstrained_log_prob_and_grad, step_size=0.005, num_leapfrog_steps=3)
     gen = torch.Generator().manual_seed(123)
