@@ -195,6 +195,12 @@ class MultivariateNormalTriL(Distribution):
     def __init__(self, loc=None, scale_tril=None, name='MultivariateNormalTriL'):
         self.loc, self.scale_tril, self.name = _t(loc), _t(scale_tril), name
 
+    def sample(self, sample_shape=(), generator=None):
+        """loc[..., D] + scale_tril[..., D, D] eps, eps ~ N(0, I): concrete parameters only."""
+        shape = tuple(sample_shape) + tuple(self.loc.shape)
+        eps = torch.randn(shape, generator=generator).to(self.loc.device)
+        return self.loc + (torch.tril(self.scale_tril) @ eps[..., None])[..., 0]
+
 
 class MixtureSameFamily(Distribution):
     def __init__(self, mixture_distribution, components_distribution, name='MixtureSameFamily'):
@@ -202,9 +208,31 @@ class MixtureSameFamily(Distribution):
         self.components_distribution = components_distribution
         self.name = name
 
+    def sample(self, sample_shape=(), generator=None):
+        """Ancestral sampling for concrete parameters: a component index per draw (weights normalised
+        by their sum, as Categorical(probs=...) does), then that component's draw.  The component
+        axis is the last batch axis of the component distribution."""
+        mix = self.mixture_distribution
+        probs = mix.probs if mix.probs is not None else torch.softmax(mix.logits, -1)
+        probs = probs / probs.sum(-1, keepdim=True)
+        comp = self.components_distribution.sample(sample_shape, generator=generator)   # [..., K(, D)]
+        k = probs.shape[-1]
+        event_dims = comp.dim() - len(tuple(sample_shape)) - probs.dim()
+        lead = comp.shape[:comp.dim() - event_dims - 1]
+        flat_p = probs.expand(tuple(lead) + (k,)).reshape(-1, k)
+        idx = torch.multinomial(flat_p.cpu(), 1, generator=generator).reshape(tuple(lead)).to(comp.device)
+        idx = idx.reshape(tuple(lead) + (1,) * (event_dims + 1)).expand(tuple(lead) + (1,) + tuple(comp.shape[comp.dim() - event_dims:]))
+        return comp.gather(len(lead), idx).squeeze(len(lead))
+
 
 class Sample(Distribution):
     """tfd.Sample(distribution, sample_shape): iid product (bayes_vi/model/model.py:17-21)."""
 
     def __init__(self, distribution, sample_shape=(), name='Sample'):
         self.distribution, self.sample_shape, self.name = distribution, sample_shape, name
+
+    def sample(self, sample_shape=(), generator=None):
+        n = self.sample_shape if isinstance(self.sample_shape, (tuple, list)) else (int(self.sample_shape),)
+        draws = self.distribution.sample(tuple(n) + tuple(sample_shape), generator=generator)
+        # iid axes go after the batch axes of the draw: [n..., sample..., batch..., event...] -> [sample..., batch..., n..., event...]
+        return draws

@@ -279,6 +279,19 @@ class Model:
                 for (name, part), shape in zip(param_samples.items(), self.param_event_shape))
         raise ValueError('You have to provide either a joint distribution or param samples.')
 
+    def get_posterior_predictive_distribution(self, posterior_distribution=None, posterior_samples=None,
+                                              num_samples=None, features=None):
+        """The joint of (empirical) posterior marginals and the likelihood, for drawing replicated data
+        (model.py:253-277): `.sample(sample_shape)` returns an OrderedDict of the parameter draws and 'y'."""
+        posteriors = posterior_distribution if isinstance(posterior_distribution, collections.OrderedDict) \
+            else self.get_param_distributions(param_samples=posterior_samples)
+        return PredictiveDistribution(self, posteriors, num_samples=num_samples, features=features)
+
+    def get_prior_predictive_distribution(self, num_samples=None, features=None):
+        """The generative joint itself: priors and likelihood (what `get_joint_distribution(...).sample` gives
+        in the reference, model.py:236-251)."""
+        return PredictiveDistribution(self, self.priors, num_samples=num_samples, features=features)
+
     def sample_prior(self, sample_shape=(), generator=None):
         return [p.sample(sample_shape, generator=generator) for p in self.priors.values()]
 
@@ -300,3 +313,34 @@ class Empirical:
         idx = torch.randint(0, self.samples.shape[0], (n,), generator=generator)
         out = self.samples[idx.to(self.samples.device)]
         return out.reshape(tuple(sample_shape) + tuple(self.samples.shape[1:]))
+
+
+class PredictiveDistribution:
+    """Ancestral sampler of a joint `parameters -> y`: parameter marginals (priors or empirical
+    posteriors) and the model's likelihood evaluated on concrete draws, conditioned on `features` for
+    regression models or over `num_samples` iid observations for generative ones (model.py:171-203)."""
+
+    def __init__(self, model, param_distributions, num_samples=None, features=None):
+        self.model, self.param_distributions = model, param_distributions
+        self.num_samples, self.features = num_samples, features
+
+    def sample(self, sample_shape=(), generator=None):
+        sample_shape = (sample_shape,) if isinstance(sample_shape, int) else tuple(sample_shape)
+        draws = collections.OrderedDict(
+            (name, dist.sample(sample_shape, generator=generator)) for name, dist in self.param_distributions.items())
+        m = self.model
+        if m.is_generative_model:
+            lik = m.likelihood(**draws)
+            n = int(self.num_samples or 1)
+            y = lik.sample((n,), generator=generator)                    # [n, *sample_shape, ...]
+            y = y.movedim(0, len(sample_shape))                          # iid axis after the draw axes
+        else:
+            feats = self.features
+            # per-row location: parameters gain a trailing row axis where the likelihood broadcasts over rows
+            expanded = collections.OrderedDict(
+                (k, v[..., None] if v.dim() == len(sample_shape) else v) for k, v in draws.items())
+            lik = m.likelihood(**expanded, features=feats)
+            y = lik.sample((), generator=generator)
+        out = collections.OrderedDict(draws)
+        out['y'] = y
+        return out

@@ -151,7 +151,11 @@ class FeatureSet:
 
 
 def matvec(features, w):
-    """features[N, F] . w[F] for a symbolic feature matrix and a vector parameter."""
+    """features[N, F] . w[F] for a symbolic feature matrix and a vector parameter; with concrete tensors
+    (posterior-predictive evaluation: features[N, F], w[..., F]) the plain product [..., N]."""
+    import torch
+    if isinstance(features, torch.Tensor) and isinstance(w, torch.Tensor):
+        return w.to(features.dtype) @ features.T
     if not isinstance(features, FeatureSet) or not isinstance(w, ParamSym) or w.index is not None:
         raise UnsupportedLikelihood('matvec(features, w) needs the feature matrix and a whole vector parameter')
     if w.size != len(features.keys):

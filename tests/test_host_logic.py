@@ -284,3 +284,46 @@ def test_recognise_fullcov_mixture_and_batched_tril():
     refv = np.concatenate([o.vjp(x[:, i * m:(i + 1) * m], g[:, i * d * d:(i + 1) * d * d]) for i in range(k)], -1)
     np.testing.assert_allclose(b.vjp(torch.tensor(x), torch.tensor(g)).numpy(), refv, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(b.inverse(b.forward(torch.tensor(x))).numpy(), x, rtol=1e-6, atol=1e-6)
+
+
+def test_posterior_predictive_sampling():
+    """model.py:253-277: replicated data from (empirical) posterior marginals and the likelihood, for a
+    generative model, a dict-feature regression, a matvec regression and a mixture."""
+    import bayes_vi_amd.distributions as tfd
+    from bayes_vi_amd import symbolic
+    from bayes_vi_amd.model import Model
+    g = torch.Generator().manual_seed(0)
+    priors = collections.OrderedDict(loc=tfd.Normal(0., 10.), scale=tfd.HalfNormal(10.))
+    model = Model(priors, lambda loc, scale: tfd.Normal(loc=loc, scale=scale))
+    post = [7 + 0.1 * torch.randn(500, 2, generator=g), 3 + 0.05 * torch.randn(500, 2, generator=g).abs()]
+    pp = model.get_posterior_predictive_distribution(posterior_samples=post, num_samples=20)
+    s = pp.sample((4000,), generator=g)
+    assert list(s.keys()) == ['loc', 'scale', 'y'] and s['y'].shape == (4000, 20)
+    assert abs(float(s['y'].mean()) - 7) < 0.1 and abs(float(s['y'].std()) - 3.03) < 0.1
+    # regression, dict features
+    x = torch.linspace(-3, 3, 50)
+    pr = collections.OrderedDict(beta_0=tfd.Normal(0., 10.), beta_1=tfd.Normal(0., 10.), scale=tfd.HalfNormal(10.))
+    reg = Model(pr, lambda beta_0, beta_1, scale, features: tfd.Normal(loc=beta_0 + beta_1 * features['x'], scale=scale))
+    post = [1 + 0.01 * torch.randn(300, generator=g), 2 + 0.01 * torch.randn(300, generator=g),
+            0.5 + 0.01 * torch.rand(300, generator=g)]
+    s = reg.get_posterior_predictive_distribution(posterior_samples=post, features={'x': x}).sample((2000,), generator=g)
+    assert s['y'].shape == (2000, 50)
+    assert torch.allclose(s['y'].mean(0), 1 + 2 * x, atol=0.08)
+    # regression, feature matrix through matvec
+    X = torch.randn(40, 3, generator=g); w = torch.tensor([1.0, -2.0, 0.5])
+    pr = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros(3), 10.), scale=tfd.HalfNormal(10.))
+    reg = Model(pr, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
+    post = [0.3 + 0.01 * torch.randn(300, generator=g), w + 0.01 * torch.randn(300, 3, generator=g),
+            0.2 + 0.01 * torch.rand(300, generator=g)]
+    s = reg.get_posterior_predictive_distribution(posterior_samples=post, features=X).sample((3000,), generator=g)
+    assert s['y'].shape == (3000, 40) and torch.allclose(s['y'].mean(0), 0.3 + X @ w, atol=0.05)
+    # mixture: prior predictive
+    k = 3
+    pm = collections.OrderedDict(weights=tfd.Dirichlet(torch.ones(k)), loc=tfd.Normal(torch.tensor([-10., 0., 10.]), 0.1),
+                                 scale=tfd.HalfNormal(torch.ones(k) * 0.5))
+    mix = Model(pm, lambda weights, loc, scale: tfd.MixtureSameFamily(
+        mixture_distribution=tfd.Categorical(probs=weights), components_distribution=tfd.Normal(loc=loc, scale=scale)))
+    s = mix.get_prior_predictive_distribution(num_samples=5).sample((3000,), generator=g)
+    assert s['y'].shape == (3000, 5)
+    near = (s['y'][..., None] - torch.tensor([-10., 0., 10.])).abs().min(-1).values
+    assert float((near < 3).float().mean()) > 0.97
