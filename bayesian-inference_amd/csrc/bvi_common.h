@@ -60,6 +60,23 @@ int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* the
                             float* grad, float* ws, hipStream_t s);
 
 #ifdef __HIPCC__
+// Sum of partials p[b * stride], b = 0 .. nb-1, in double and in a fixed order.  WAVE = false: the calling
+// thread adds them one by one; WAVE = true: the 64 lanes of the calling wave stride over b and combine by
+// a butterfly (every lane returns the total) -- for the many-row-block launches of the streaming kernels,
+// where a single thread would add up to 2048 partials serially.
+template <bool WAVE>
+__device__ __forceinline__ double bvi_sum_partials(const float* __restrict__ p, int nb, int64_t stride) {
+  double s = 0.0;
+  if (!WAVE) {
+    for (int b = 0; b < nb; ++b) s += (double)p[(int64_t)b * stride];
+    return s;
+  }
+  for (int b = threadIdx.x & 63; b < nb; b += 64) s += (double)p[(int64_t)b * stride];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  return s;
+}
+
 // Sum over the lanes that share (lane % CP): butterfly over the upper lane bits.
 template <int CP>
 __device__ __forceinline__ float bvi_reduce_over_rowsubs(float v) {

@@ -114,23 +114,25 @@ __global__ __launch_bounds__(256) void gmm1d_kernel(const float* __restrict__ y,
   }
 }
 
+// one thread (WAVE = false) or one wave (WAVE = true) per gradient entry
+template <bool WAVE>
 __global__ void gmm1d_finalize(const float* __restrict__ partials, int nb, int64_t n, int k,
                                const float* __restrict__ theta, int C, float* __restrict__ logp,
                                float* __restrict__ grad) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = WAVE ? (blockIdx.x * blockDim.x + threadIdx.x) >> 6 : blockIdx.x * blockDim.x + threadIdx.x;
   const int q3 = 3 * k, qreal = 1 + 3 * k;
   if (idx >= C * q3) return;
   const int c = idx / q3, j = idx - c * q3;  // j indexes the gradient entry (w | mu | scale)
   const int part = j / k, kk = j - part * k;
   const float* th = theta + (int64_t)c * q3;
-  double a0 = 0.0, ax = 0.0, l2 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    const float* p = partials + ((int64_t)b * C + c) * qreal;
-    a0 += (double)p[1 + kk];
-    if (part == 1) ax += (double)p[1 + k + kk];
-    if (part == 2) ax += (double)p[1 + 2 * k + kk];
-    if (j == 0) l2 += (double)p[0];
-  }
+  const float* pc = partials + (int64_t)c * qreal;
+  const int64_t stride = (int64_t)C * qreal;
+  const double a0 = bvi_sum_partials<WAVE>(pc + 1 + kk, nb, stride);
+  double ax = 0.0, l2 = 0.0;
+  if (part == 1) ax = bvi_sum_partials<WAVE>(pc + 1 + k + kk, nb, stride);
+  if (part == 2) ax = bvi_sum_partials<WAVE>(pc + 1 + 2 * k + kk, nb, stride);
+  if (j == 0) l2 = bvi_sum_partials<WAVE>(pc, nb, stride);
+  if (WAVE && (threadIdx.x & 63) != 0) return;
   if (j == 0) logp[c] = (float)(l2 * 0.6931471805599453);
   if (!grad) return;
   const double sc = (double)th[2 * k + kk];
@@ -179,8 +181,12 @@ int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c
   else gmm1d_dispatch_cp<16>(cp, grid, s, y, n, k, theta, c, ws);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * 3 * k;
-  hipLaunchKernelGGL(gmm1d_finalize, dim3(bvi_ceil_div(tot, 128)), dim3(128), 0, s, (const float*)ws, nb, n, k,
-                     theta, c, logp, grad);
+  if (nb > 32)
+    hipLaunchKernelGGL(gmm1d_finalize<true>, dim3(bvi_ceil_div(tot, 4)), dim3(256), 0, s, (const float*)ws, nb, n, k,
+                       theta, c, logp, grad);
+  else
+    hipLaunchKernelGGL(gmm1d_finalize<false>, dim3(bvi_ceil_div(tot, 128)), dim3(128), 0, s, (const float*)ws, nb, n,
+                       k, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

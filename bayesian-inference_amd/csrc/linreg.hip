@@ -281,17 +281,18 @@ __global__ __launch_bounds__(256) void linreg_f32_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------
 // finalize: fixed-order reduction over row blocks (double) + scaling.
-// One thread per (chain, raw-sum index).
+// One thread, or for many row blocks one wave, per (chain, raw-sum index).
 // ---------------------------------------------------------------------------
+template <bool WAVE>
 __global__ void linreg_finalize(const float* __restrict__ partials, int nb, int64_t n, int d,
                                 const float* __restrict__ theta, int C, float* __restrict__ logp,
                                 float* __restrict__ grad) {
   const int q2 = d + 2;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = WAVE ? (blockIdx.x * blockDim.x + threadIdx.x) >> 6 : blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= C * q2) return;
   const int c = idx / q2, q = idx - c * q2;
-  double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += (double)partials[((int64_t)b * C + c) * q2 + q];
+  const double s = bvi_sum_partials<WAVE>(partials + (int64_t)c * q2 + q, nb, (int64_t)C * q2);
+  if (WAVE && (threadIdx.x & 63) != 0) return;
   const double sc = (double)theta[(int64_t)c * q2 + d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   if (q == 0) {
@@ -300,6 +301,16 @@ __global__ void linreg_finalize(const float* __restrict__ partials, int nb, int6
   } else if (grad) {
     grad[(int64_t)c * q2 + (q - 1)] = (float)(s * inv2);
   }
+}
+
+static void launch_linreg_finalize(int tot, hipStream_t s, const float* ws, int nb, int64_t n, int d,
+                                   const float* theta, int c, float* logp, float* grad) {
+  if (nb > 32)
+    hipLaunchKernelGGL(linreg_finalize<true>, dim3(bvi_ceil_div(tot, 4)), dim3(256), 0, s, ws, nb, n, d, theta, c,
+                       logp, grad);
+  else
+    hipLaunchKernelGGL(linreg_finalize<false>, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, ws, nb, n, d, theta, c,
+                       logp, grad);
 }
 
 // ---------------------------------------------------------------------------
@@ -363,8 +374,7 @@ int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* 
                                           ws, &nb, s);
   if (st != BVI_OK) return st;
   const int tot = c * (d + 2);
-  hipLaunchKernelGGL(linreg_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws, nb, n, d,
-                     theta, c, logp, grad);
+  launch_linreg_finalize(tot, s, ws, nb, n, d, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
@@ -408,8 +418,7 @@ int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const fl
     BVI_HIP_CHECK_LAUNCH();
   }
   const int tot = c * (d + 2);
-  hipLaunchKernelGGL(linreg_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws, nb, n, d,
-                     theta, c, logp, grad);
+  launch_linreg_finalize(tot, s, ws, nb, n, d, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

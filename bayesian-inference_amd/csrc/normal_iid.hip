@@ -75,16 +75,16 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
   }
 }
 
+// one thread (WAVE = false) or one wave (WAVE = true) per chain
+template <bool WAVE>
 __global__ void normal_iid_finalize(const float* __restrict__ partials, int nb, int64_t n,
                                     const float* __restrict__ theta, int C, float* __restrict__ logp,
                                     float* __restrict__ grad) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = WAVE ? (blockIdx.x * blockDim.x + threadIdx.x) >> 6 : blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s1 += (double)partials[((int64_t)b * C + c) * 2];
-    s2 += (double)partials[((int64_t)b * C + c) * 2 + 1];
-  }
+  const double s1 = bvi_sum_partials<WAVE>(partials + (int64_t)c * 2, nb, (int64_t)C * 2);
+  const double s2 = bvi_sum_partials<WAVE>(partials + (int64_t)c * 2 + 1, nb, (int64_t)C * 2);
+  if (WAVE && (threadIdx.x & 63) != 0) return;
   const double sc = (double)theta[2 * c + 1], nn = (double)n;
   const double inv2 = 1.0 / (sc * sc);
   logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
@@ -113,8 +113,12 @@ int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, 
     default: hipLaunchKernelGGL(normal_iid_kernel<64>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
   }
   BVI_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(normal_iid_finalize, dim3(bvi_ceil_div(c, 128)), dim3(128), 0, s, (const float*)ws, nb, n,
-                     theta, c, logp, grad);
+  if (nb > 32)
+    hipLaunchKernelGGL(normal_iid_finalize<true>, dim3(bvi_ceil_div(c, 4)), dim3(256), 0, s, (const float*)ws, nb, n,
+                       theta, c, logp, grad);
+  else
+    hipLaunchKernelGGL(normal_iid_finalize<false>, dim3(bvi_ceil_div(c, 128)), dim3(128), 0, s, (const float*)ws, nb,
+                       n, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
