@@ -340,7 +340,7 @@ size_t bvi_ws_linreg(int64_t n, int c, int d) {
     const int nb2 = bvi_linreg_bf16x3_blocks(n, c);
     nb = nb2 > nb ? nb2 : nb;
   }
-  nb = nb < 257 ? 257 : nb;     // the f16-piece kernel: up to 256 row blocks + one scale per chain block
+  nb = nb < 513 ? 513 : nb;     // the f16-piece kernel: up to 512 row blocks + one scale per chain block
   return (size_t)nb * c * (d + 2) * sizeof(float);
 }
 

@@ -50,7 +50,6 @@ namespace {
 
 constexpr int kTileRows = 128;             // rows staged per barrier; processed as 64-row halves
 constexpr int kHeader = 1024;
-constexpr int kWaves = 8;                 // waves per workgroup; the workgroup owns 32 * kWaves chains
 constexpr int kMaxRowBlocks = 256;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -546,38 +545,44 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   return BVI_OK;
 }
 
-int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
-                          float* grad, float* ws, hipStream_t s) {
-  if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
-  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
-  const int dp = plane_cols(d);
-  constexpr int cpb = 32 * kWaves;
+template <int D, int NW>
+static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* theta, int c, float* logp, float* grad,
+                      float* ws, hipStream_t s) {
+  constexpr int cpb = 32 * NW;
+  // NW = 8: one workgroup per CU; NW = 4 (at most 128 chains): two per CU, each on its own row blocks
+  constexpr int max_blocks = NW == 8 ? kMaxRowBlocks : 2 * kMaxRowBlocks;
   const int ncb = bvi_ceil_div(c, cpb);
-  int per8 = (kMaxRowBlocks / 8) / ncb;      // one workgroup per CU: ncb * nrb = 256 while ncb <= 32
+  int per8 = (max_blocks / 8) / ncb;
   if (per8 < 1) per8 = 1;
   const int nrb = 8 * per8;
-  dim3 grid(ncb * nrb);
-  const unsigned char* pk = (const unsigned char*)packed;
   // workspace: partials [nrb][c][d+2], then one residual scale per chain block
   float* ublk = ws + (size_t)nrb * c * (d + 2);
-  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * dp + 2 * kTileRows * 4);
-  static bool lds_ok[2] = {false, false};   // > 64 KB of dynamic LDS has to be allowed once per kernel
-  if (!lds_ok[dp == 64]) {
-    const void* fn = dp == 64 ? (const void*)&linreg_f16_kernel<64, kWaves> : (const void*)&linreg_f16_kernel<32, kWaves>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * D + 2 * kTileRows * 4);
+  static bool lds_ok = false;                 // > 64 KB of dynamic LDS has to be allowed once per kernel
+  if (!lds_ok) {
+    hipError_t e = hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_ok[dp == 64] = true;
+    lds_ok = true;
   }
-  if (dp == 64)
-    hipLaunchKernelGGL((linreg_f16_kernel<64, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, d, theta, c, ncb,
-                       nrb, ws, ublk);
-  else
-    hipLaunchKernelGGL((linreg_f16_kernel<32, kWaves>), grid, dim3(64 * kWaves), lds, s, pk, n, d, theta, c, ncb,
-                       nrb, ws, ublk);
+  hipLaunchKernelGGL((linreg_f16_kernel<D, NW>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb,
+                     ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * (d + 2);
   hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws,
                      (const float*)ublk, cpb, nrb, n, d, pk, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
+}
+
+int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
+                          float* grad, float* ws, hipStream_t s) {
+  if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
+  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+  const unsigned char* pk = (const unsigned char*)packed;
+  const bool wide = plane_cols(d) == 64, few = c <= 128;
+  if (wide) return few ? launch_f16<64, 4>(pk, n, d, theta, c, logp, grad, ws, s)
+                       : launch_f16<64, 8>(pk, n, d, theta, c, logp, grad, ws, s);
+  return few ? launch_f16<32, 4>(pk, n, d, theta, c, logp, grad, ws, s)
+             : launch_f16<32, 8>(pk, n, d, theta, c, logp, grad, ws, s);
 }

@@ -226,13 +226,14 @@ def test_linear_regression_auto_runs_f16_pieces(nat, ws, gpu_device):
     X, y, th = _linreg_case(rng, 20000, 64, 256)
     Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
     lik = LinearRegression(Xd, yd)
-    assert lik.matrix_core_format(256) == nat.PACK_F16 and lik.matrix_core_format(64) is None
+    assert lik.matrix_core_format(256) == nat.PACK_F16 and lik.matrix_core_format(40) == nat.PACK_F16 \
+        and lik.matrix_core_format(32) is None
     lp, g = lik.logp_grad(thd)
     pk = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
     lp_p, g_p = nat.linreg_packed_logp_grad(pk, 20000, 64, thd, ws, fmt=nat.PACK_F16)
     assert torch.equal(lp, lp_p) and torch.equal(g, g_p)
-    lp_s, g_s = lik.logp_grad(thd[:64])
-    lp_f, g_f = nat.linreg_logp_grad(Xd, yd, thd[:64], ws, precision=nat.PREC_F32)
+    lp_s, g_s = lik.logp_grad(thd[:32].contiguous())
+    lp_f, g_f = nat.linreg_logp_grad(Xd, yd, thd[:32].contiguous(), ws, precision=nat.PREC_F32)
     assert torch.equal(lp_s, lp_f) and torch.equal(g_s, g_f)
 
 
