@@ -15,7 +15,7 @@ FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV = 0, 1, 2, 3
 PREC_AUTO, PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 PACK_BF16X3, PACK_F16 = 0, 1
 
-BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED = 0, 1, 2, 3
+BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED, BIJ_FILL_SCALE_TRIL = 0, 1, 2, 3, 4
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 
@@ -23,7 +23,20 @@ MAX_PARAM_BLOCKS = 16
 class ParamBlock(ctypes.Structure):
     """struct bvi_param_block of include/bvi.h."""
     _fields_ = [('bijector', ctypes.c_int32), ('size', ctypes.c_int32), ('prior', ctypes.c_int32),
-                ('a', ctypes.c_float), ('b', ctypes.c_float)]
+                ('a', ctypes.c_float), ('b', ctypes.c_float), ('dim', ctypes.c_int32), ('shift', ctypes.c_float)]
+
+
+NUTS_ACTIVE, NUTS_BUILDING, NUTS_TURNED, NUTS_DIVERGED, NUTS_MOVED, NUTS_FORWARD = 1, 2, 4, 8, 16, 32
+_NUTS_FLOAT_ARRAYS = ('z', 'lp', 'grad', 'q', 'p', 'gq', 'lpq', 'ql', 'pl', 'gl', 'qr', 'pr', 'gr', 'sub_q', 'sub_g',
+                      'sub_lp', 'ck_q', 'ck_p', 'h0', 'log_w', 'sub_log_w', 'sum_acc', 'log_u_sub', 'se')
+_NUTS_INT_ARRAYS = ('n_leap', 'leaf_ctr', 'flags')
+
+
+class NutsState(ctypes.Structure):
+    """struct bvi_nuts_state of include/bvi.h."""
+    _fields_ = ([('n_chains', ctypes.c_int), ('n_unconstrained', ctypes.c_int), ('max_tree_depth', ctypes.c_int),
+                 ('step_size', ctypes.c_float), ('max_energy_diff', ctypes.c_float)]
+                + [(n, ctypes.c_void_p) for n in _NUTS_FLOAT_ARRAYS + _NUTS_INT_ARRAYS])
 
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'libbvi_hip.so')
@@ -65,6 +78,13 @@ def lib():
         l.bvi_posterior_assemble.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_leapfrog_pre.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp]
         l.bvi_leapfrog_post.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_leapfrog_pre_chainwise.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp]
+        l.bvi_leapfrog_post_chainwise.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        nsp = ctypes.POINTER(NutsState)
+        l.bvi_nuts_begin.argtypes = [nsp, u64, u64, vp]
+        l.bvi_nuts_subtree_begin.argtypes = [nsp, u64, u64, i32, vp]
+        l.bvi_nuts_leaf.argtypes = [nsp, u64, u64, i32, vp, vp]
+        l.bvi_nuts_subtree_end.argtypes = [nsp, vp, vp]
         l.bvi_hmc_begin.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_hmc_end.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_hmc_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, vp, i32, i32, u64, u64, i32,
@@ -76,7 +96,9 @@ def lib():
         l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]
         l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
         for name in ('bvi_constrain', 'bvi_posterior_assemble', 'bvi_leapfrog_pre', 'bvi_leapfrog_post',
-                     'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_hmc_fused', 'bvi_nuts_fused', 'bvi_rwm_fused', 'bvi_philox_uint32', 'bvi_philox_normal'):
+                     'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_hmc_fused', 'bvi_nuts_fused', 'bvi_rwm_fused', 'bvi_philox_uint32', 'bvi_philox_normal',
+                     'bvi_leapfrog_pre_chainwise', 'bvi_leapfrog_post_chainwise', 'bvi_nuts_begin',
+                     'bvi_nuts_subtree_begin', 'bvi_nuts_leaf', 'bvi_nuts_subtree_end'):
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
@@ -197,12 +219,14 @@ def linreg_packed_logp_grad(packed, n, d, theta, ws: Workspace, want_grad=True, 
 
 
 def make_blocks(specs):
-    """specs: list of (bijector, size, prior, a, b) -> ctypes array of bvi_param_block."""
+    """specs: list of (bijector, size, prior, a, b[, dim, shift]) -> ctypes array of bvi_param_block."""
     if len(specs) > MAX_PARAM_BLOCKS:
         raise BviError('at most %d parameter blocks on the device path' % MAX_PARAM_BLOCKS)
     arr = (ParamBlock * len(specs))()
-    for i, (bij, size, prior, a, b) in enumerate(specs):
-        arr[i] = ParamBlock(bij, size, prior, a, b)
+    for i, spec in enumerate(specs):
+        bij, size, prior, a, b = spec[:5]
+        dim, shift = spec[5:7] if len(spec) > 5 else (0, 0.0)
+        arr[i] = ParamBlock(bij, size, prior, a, b, dim, shift)
     return arr
 
 

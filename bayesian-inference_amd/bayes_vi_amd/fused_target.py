@@ -222,7 +222,8 @@ class Posterior:
         specs = []
         for prior, bij, size in zip(self.priors, self.bijector.bijectors, self.csizes):
             kinds = {_bij.Identity: _native.BIJ_IDENTITY, _bij.Softplus: _native.BIJ_SOFTPLUS,
-                     _bij.Exp: _native.BIJ_EXP, _bij.SoftmaxCentered: _native.BIJ_SOFTMAX_CENTERED}
+                     _bij.Exp: _native.BIJ_EXP, _bij.SoftmaxCentered: _native.BIJ_SOFTMAX_CENTERED,
+                     _bij.FillScaleTriL: _native.BIJ_FILL_SCALE_TRIL}
             if type(bij) not in kinds:
                 specs = None
                 break
@@ -242,7 +243,13 @@ class Posterior:
             if spec[0] is None or spec[1] is None or spec[2] is None:
                 specs = None
                 break
-            specs.append((kinds[type(bij)], size, spec[0], spec[1], spec[2]))
+            if isinstance(bij, _bij.FillScaleTriL):
+                if spec[0] == _native.PRIOR_DIRICHLET or size != bij.batch * bij.d * bij.d:
+                    specs = None
+                    break
+                specs.append((kinds[type(bij)], size, spec[0], spec[1], spec[2], bij.d, float(bij.diag_shift)))
+            else:
+                specs.append((kinds[type(bij)], size, spec[0], spec[1], spec[2]))
         if specs is not None and len(specs) > _native.MAX_PARAM_BLOCKS:
             specs = None
         self._blocks = _native.make_blocks(specs) if specs is not None else None
@@ -265,6 +272,24 @@ class Posterior:
 
     # ---- unconstrained space: what TransformedTransitionKernel evaluates (mcmc.py:153-156) ----
     def unconstrained_log_prob_and_grad(self, z, want_grad=True):
+        """log pi(z) = log pi(f(z)) + fldj(z) and its gradient in unconstrained space, z[C, Pu]: what
+        tfp.mcmc.TransformedTransitionKernel makes of the target closure (mcmc.py:153-156).  With built-in
+        priors and bijectors on the GPU this is three launches -- bvi_constrain, the fused data pass,
+        bvi_posterior_assemble --; other models compose the same quantities from the bijector objects."""
+        blocks = self.device_blocks() if z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 else None
+        if blocks is not None:
+            lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
+            z = z.contiguous()
+            c = z.shape[0]
+            theta = torch.empty(c, self.n_constrained, dtype=torch.float32, device=z.device)
+            _native.check(lib.bvi_constrain(blocks, len(blocks), c, ptr(z), ptr(theta), st), 'bvi_constrain')
+            ll, gl = self.likelihood.logp_grad(theta, want_grad)
+            lp = torch.empty(c, dtype=torch.float32, device=z.device)
+            gz = torch.empty_like(z) if want_grad else None
+            _native.check(lib.bvi_posterior_assemble(blocks, len(blocks), c, ptr(z), ptr(theta), ptr(ll),
+                                                     ptr(gl) if want_grad else None, ptr(lp), ptr(gz), st),
+                          'bvi_posterior_assemble')
+            return lp, gz
         theta = self.bijector.forward(z)
         lp, g = self.log_prob_and_grad(theta, want_grad)
         lp = lp + self.bijector.forward_log_det_jacobian(z)

@@ -267,3 +267,97 @@ class FusedRandomWalkMetropolisKernel:
     def one_step(self, z, state, generator=None):
         zs, z, state, tr = self.many_steps(z, state, 1, generator)
         return z, state, {k: v[0] for k, v in tr.items()}
+
+
+class BatchedDeviceNoUTurnSamplerKernel:
+    """NUTS for datasets that need the batched likelihood kernels (any size, row shards over GPUs):
+    the tree bookkeeping of every chain runs in the bvi_nuts_* kernels, the leapfrog halves in
+    bvi_leapfrog_{pre,post}_chainwise with one signed step size per chain, and per leapfrog step the
+    host enqueues five launches (pre, fused data pass + finalize, post, leaf) and reads back one word.
+    Chains advance in lock-step, so one transition costs (max over chains of leapfrogs) data passes.
+    Same algorithm, trace fields and Philox draws as `FusedNoUTurnSamplerKernel`
+    (tfp.mcmc.NoUTurnSampler of bayes_vi/inference/mcmc/transition_kernels.py:238-246)."""
+    trace_names = ('is_accepted', 'target_log_prob', 'log_accept_ratio', 'step_size',
+                   'leapfrogs_taken', 'has_divergence', 'energy')
+
+    def __init__(self, posterior, step_size=0.01, max_tree_depth=5, max_energy_diff=1000.0, seed=0):
+        self.posterior = posterior
+        self.blocks = posterior.device_blocks()
+        if self.blocks is None:
+            raise _native.BviError('this model has priors/bijectors outside the device-side posterior assembly')
+        if not 1 <= int(max_tree_depth) <= 10:
+            raise _native.BviError('max_tree_depth must be in 1..10 on the device path')
+        self.nb = len(self.blocks)
+        self.step_size = float(step_size)
+        self.max_tree_depth = int(max_tree_depth)
+        self.max_energy_diff = float(max_energy_diff)
+        self.seed = int(seed)
+        self.transition = 0
+        self._bufs = None
+
+    def _buffers(self, c, pu, device):
+        if self._bufs is None or self._bufs['q'].shape != (c, pu):
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+            i = lambda *s: torch.empty(*s, dtype=torch.int32, device=device)
+            b = {n: f(c, pu) for n in ('q', 'p', 'gq', 'ql', 'pl', 'gl', 'qr', 'pr', 'gr', 'sub_q', 'sub_g')}
+            b.update({n: f(c) for n in ('lpq', 'sub_lp', 'h0', 'log_w', 'sub_log_w', 'sum_acc', 'log_u_sub', 'se')})
+            b.update({n: i(c) for n in ('n_leap', 'leaf_ctr', 'flags')})
+            b['ck_q'], b['ck_p'] = f(self.max_tree_depth + 1, c, pu), f(self.max_tree_depth + 1, c, pu)
+            b['theta'] = f(c, self.posterior.n_constrained)
+            b['any'] = i((1 << self.max_tree_depth) + self.max_tree_depth)
+            self._bufs = b
+        return self._bufs
+
+    def bootstrap(self, z):
+        lp, g = self.posterior.unconstrained_log_prob_and_grad(z, True)
+        return {'target_log_prob': lp.contiguous(), 'grad': g.contiguous()}
+
+    def one_step(self, z, state, generator=None):
+        lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
+        z = z.clone().contiguous()          # the kernels update position, gradient and log-prob in place
+        lp = state['target_log_prob'].clone()
+        g = state['grad'].clone()
+        c, pu = z.shape
+        b = self._buffers(c, pu, z.device)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        step = self.transition
+        self.transition += 1
+        s = _native.NutsState(n_chains=c, n_unconstrained=pu, max_tree_depth=self.max_tree_depth,
+                              step_size=self.step_size, max_energy_diff=self.max_energy_diff,
+                              z=z.data_ptr(), lp=lp.data_ptr(), grad=g.data_ptr(),
+                              **{n: b[n].data_ptr() for n in _native._NUTS_FLOAT_ARRAYS + _native._NUTS_INT_ARRAYS
+                                 if n not in ('z', 'lp', 'grad')})
+        flag, nflag = b['any'], 0
+        flag.zero_()
+        _native.check(lib.bvi_nuts_begin(s, seed, step, st), 'bvi_nuts_begin')
+        lik = self.posterior.likelihood
+        for depth in range(self.max_tree_depth):
+            _native.check(lib.bvi_nuts_subtree_begin(s, seed, step, depth, st), 'bvi_nuts_subtree_begin')
+            n_leaves = 1 << depth
+            for leaf in range(n_leaves):
+                _native.check(lib.bvi_leapfrog_pre_chainwise(self.blocks, self.nb, c, ptr(b['se']), ptr(b['q']),
+                                                             ptr(b['p']), ptr(b['gq']), ptr(b['theta']), st),
+                              'bvi_leapfrog_pre_chainwise')
+                ll, gl = lik.logp_grad(b['theta'], True)      # fused data pass (+ all-reduce over row shards)
+                _native.check(lib.bvi_leapfrog_post_chainwise(self.blocks, self.nb, c, ptr(b['se']), ptr(b['q']),
+                                                              ptr(b['p']), ptr(b['theta']), ptr(ll), ptr(gl),
+                                                              ptr(b['lpq']), ptr(b['gq']), st),
+                              'bvi_leapfrog_post_chainwise')
+                _native.check(lib.bvi_nuts_leaf(s, seed, step, leaf, ptr(flag[nflag:]), st), 'bvi_nuts_leaf')
+                nflag += 1
+                # The host only needs to know when NO chain is building any more.  U-turns inside a subtree
+                # are found at odd leaves, so that is when the word is read back (a divergence at an even
+                # leaf is noticed one frozen leapfrog late); after the last leaf the subtree ends either way.
+                if (leaf & 1) and leaf + 1 < n_leaves and int(flag[nflag - 1].item()) == 0:
+                    break
+            _native.check(lib.bvi_nuts_subtree_end(s, ptr(flag[nflag:]), st), 'bvi_nuts_subtree_end')
+            nflag += 1
+            if depth + 1 < self.max_tree_depth and int(flag[nflag - 1].item()) == 0:
+                break
+        fl = b['flags']
+        n_leap = b['n_leap'].to(torch.int64)
+        lr = torch.log(torch.clamp(b['sum_acc'] / torch.clamp(n_leap, min=1).to(z.dtype), min=1e-30))
+        trace = {'is_accepted': (fl & _native.NUTS_MOVED) != 0, 'target_log_prob': lp, 'log_accept_ratio': lr,
+                 'step_size': torch.full((), self.step_size, dtype=z.dtype), 'leapfrogs_taken': n_leap,
+                 'has_divergence': (fl & _native.NUTS_DIVERGED) != 0, 'energy': -lp}
+        return z, {'target_log_prob': lp, 'grad': g}, trace

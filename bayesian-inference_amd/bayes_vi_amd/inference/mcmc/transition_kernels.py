@@ -81,11 +81,14 @@ class NoUTurnSampler(TransitionKernel):
         post = getattr(target, '__self__', None)
         if post is not None and hasattr(post, 'device_blocks') and post.likelihood.device.type == 'cuda' \
                 and self.unrolled_leapfrog_steps == 1 and self.max_tree_depth <= 10:
-            from .device_hmc import FusedNoUTurnSamplerKernel, fused_family
+            from .device_hmc import BatchedDeviceNoUTurnSamplerKernel, FusedNoUTurnSamplerKernel, fused_family
             fam = fused_family(post)
             if fam is not None:
                 return FusedNoUTurnSamplerKernel(post, fam, self.step_size, self.max_tree_depth,
                                                  self.max_energy_diff)
+            if post.device_blocks() is not None:    # any size: tree bookkeeping on the device, batched data passes
+                return BatchedDeviceNoUTurnSamplerKernel(post, self.step_size, self.max_tree_depth,
+                                                         self.max_energy_diff)
         return samplers.NoUTurnSamplerKernel(target, self.step_size, self.max_tree_depth, self.max_energy_diff,
                                              self.unrolled_leapfrog_steps)
 

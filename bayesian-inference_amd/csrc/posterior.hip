@@ -126,6 +126,41 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
           z[oz + j] = fmaf(eps, pj, z[oz + j]);
         }
       }
+    } else if (b.bijector == BVI_BIJ_FILL_SCALE_TRIL) {
+      // lanes stride over the constrained entries; every lower-triangular entry reads (and, in place,
+      // updates) its own packed element, entries above the diagonal are structural zeros
+      const int d = b.dim, dd = d * d, m = d * (d + 1) / 2;
+      for (int t = lane; t < b.size; t += 64) {
+        const int mat = t / dd, f = t - mat * dd, i = f / d, j = f - i * d;
+        float th = 0.f, fl = 0.f, dth = 1.f, dfl = 0.f, x = 0.f;
+        const int src = oz + mat * m + fill_triangular_src(d, f);
+        if (j <= i) {
+          x = zval(src);
+          th = x;
+          if (i == j) {
+            th = softplusf(x) + b.shift; fl = -softplusf(-x); dth = sigmoidf(x); dfl = sigmoidf(-x);
+          }
+        }
+        theta[ot + t] = th;
+        if (ASSEMBLE) {
+          float sc;
+          part += fl + prior_elem(b, t, th, &sc);
+          if (gl) {
+            const float gt = gl[ot + t] + sc;
+            gl[ot + t] = gt;
+            if (gz && j <= i) {
+              const float gzj = fmaf(gt, dth, dfl);
+              gz[src] = gzj;
+              if (HALFSTEP) p[src] = fmaf(0.5f * eps, gzj, p[src]);
+            }
+          }
+        }
+        if (PRE && j <= i) {
+          const float pj = fmaf(0.5f * eps, g_old[src], p[src]);
+          p[src] = pj;
+          z[src] = x;
+        }
+      }
     } else {
       for (int j = lane; j < b.size; j += 64) {
         const float x = zval(oz + j);
@@ -188,20 +223,34 @@ __global__ __launch_bounds__(64) void assemble_kernel(Blocks bl, int C, int P, i
 
 // leapfrog "pre": p += eps/2 g; z += eps p; theta = f(z)
 __global__ __launch_bounds__(64) void leapfrog_pre_kernel(Blocks bl, int C, int P, int Pu, float eps,
+                                                          const float* __restrict__ eps_chain,
                                                           float* __restrict__ z, float* __restrict__ p,
                                                           const float* __restrict__ g, float* __restrict__ theta) {
   const int c = blockIdx.x;
+  if (eps_chain) {
+    eps = eps_chain[c];                   // per-chain signed step; 0 = frozen chain: only theta = f(z) is rewritten
+    if (eps == 0.f) {
+      chain_work<false, false, false>(bl, P, Pu, 0.f, z + (int64_t)c * Pu, nullptr, nullptr, theta + (int64_t)c * P,
+                                      nullptr, nullptr, nullptr, nullptr, c);
+      return;
+    }
+  }
   chain_work<true, false, false>(bl, P, Pu, eps, z + (int64_t)c * Pu, p + (int64_t)c * Pu, g + (int64_t)c * Pu,
                                  theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c);
 }
 
 // leapfrog "post": assemble lp, g at the new z, then p += eps/2 g
 __global__ __launch_bounds__(64) void leapfrog_post_kernel(Blocks bl, int C, int P, int Pu, float eps,
+                                                           const float* __restrict__ eps_chain,
                                                            const float* __restrict__ z, float* __restrict__ p,
                                                            float* __restrict__ theta, const float* __restrict__ ll,
                                                            float* __restrict__ gl, float* __restrict__ lp,
                                                            float* __restrict__ g) {
   const int c = blockIdx.x;
+  if (eps_chain) {
+    eps = eps_chain[c];
+    if (eps == 0.f) return;               // frozen chain: momentum, log density and gradient stay as they are
+  }
   chain_work<false, true, true>(bl, P, Pu, eps, const_cast<float*>(z) + (int64_t)c * Pu, p + (int64_t)c * Pu,
                                 nullptr, theta + (int64_t)c * P, ll, gl + (int64_t)c * P, lp, g + (int64_t)c * Pu, c);
 }
@@ -288,7 +337,7 @@ int bvi_constrain(const bvi_param_block* blocks, int n_blocks, int n_chains, con
                   void* stream) {
   Blocks bl;
   int P, Pu;
-  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
+  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !theta || n_chains < 1) return BVI_ERR_ARG;
   hipLaunchKernelGGL(constrain_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
@@ -301,7 +350,7 @@ int bvi_posterior_assemble(const bvi_param_block* blocks, int n_blocks, int n_ch
                            const float* loglik, float* grad_theta, float* lp, float* grad_z, void* stream) {
   Blocks bl;
   int P, Pu;
-  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
+  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !theta || !loglik || !lp || n_chains < 1 || (grad_z && !grad_theta)) return BVI_ERR_ARG;
   hipLaunchKernelGGL(assemble_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
@@ -310,31 +359,57 @@ int bvi_posterior_assemble(const bvi_param_block* blocks, int n_blocks, int n_ch
   return BVI_OK;
 }
 
-int bvi_leapfrog_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, float* z, float* p,
-                     const float* grad_z, float* theta, void* stream) {
+static int launch_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                      const float* step_sizes, float* z, float* p, const float* grad_z, float* theta, void* stream) {
   Blocks bl;
   int P, Pu;
-  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
+  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !p || !grad_z || !theta || n_chains < 1) return BVI_ERR_ARG;
   hipLaunchKernelGGL(leapfrog_pre_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
-                     Pu, step_size, z, p, grad_z, theta);
+                     Pu, step_size, step_sizes, z, p, grad_z, theta);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
+}
+
+static int launch_post(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
+                       const float* step_sizes, const float* z, float* p, float* theta, const float* loglik,
+                       float* grad_theta, float* lp, float* grad_z, void* stream) {
+  Blocks bl;
+  int P, Pu;
+  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
+  if (st != BVI_OK) return st;
+  if (!z || !p || !theta || !loglik || !grad_theta || !lp || !grad_z || n_chains < 1) return BVI_ERR_ARG;
+  hipLaunchKernelGGL(leapfrog_post_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
+                     Pu, step_size, step_sizes, z, p, theta, loglik, grad_theta, lp, grad_z);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
+int bvi_leapfrog_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, float* z, float* p,
+                     const float* grad_z, float* theta, void* stream) {
+  return launch_pre(blocks, n_blocks, n_chains, step_size, nullptr, z, p, grad_z, theta, stream);
 }
 
 int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, const float* z,
                       float* p, float* theta, const float* loglik, float* grad_theta, float* lp, float* grad_z,
                       void* stream) {
-  Blocks bl;
-  int P, Pu;
-  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu);
-  if (st != BVI_OK) return st;
-  if (!z || !p || !theta || !loglik || !grad_theta || !lp || !grad_z || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(leapfrog_post_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
-                     Pu, step_size, z, p, theta, loglik, grad_theta, lp, grad_z);
-  BVI_HIP_CHECK_LAUNCH();
-  return BVI_OK;
+  return launch_post(blocks, n_blocks, n_chains, step_size, nullptr, z, p, theta, loglik, grad_theta, lp, grad_z,
+                     stream);
+}
+
+int bvi_leapfrog_pre_chainwise(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* step_sizes,
+                               float* z, float* p, const float* grad_z, float* theta, void* stream) {
+  if (!step_sizes) return BVI_ERR_ARG;
+  return launch_pre(blocks, n_blocks, n_chains, 0.f, step_sizes, z, p, grad_z, theta, stream);
+}
+
+int bvi_leapfrog_post_chainwise(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* step_sizes,
+                                const float* z, float* p, float* theta, const float* loglik, float* grad_theta,
+                                float* lp, float* grad_z, void* stream) {
+  if (!step_sizes) return BVI_ERR_ARG;
+  return launch_post(blocks, n_blocks, n_chains, 0.f, step_sizes, z, p, theta, loglik, grad_theta, lp, grad_z,
+                     stream);
 }
 
 int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* z,

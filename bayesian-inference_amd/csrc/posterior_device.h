@@ -17,8 +17,16 @@ struct Blocks {
 __device__ __forceinline__ float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-__device__ __forceinline__ int usize_of(const bvi_param_block& b) {
+__host__ __device__ __forceinline__ int usize_of(const bvi_param_block& b) {
+  if (b.bijector == BVI_BIJ_FILL_SCALE_TRIL) return b.size / (b.dim * b.dim) * (b.dim * (b.dim + 1) / 2);
   return b.bijector == BVI_BIJ_SOFTMAX_CENTERED ? b.size - 1 : b.size;
+}
+
+// tfp.math.fill_triangular: entry (i, j), j <= i, of the d x d matrix is element
+// reshape(concat(x[d:], reverse(x)), [d, d])[i][j] of the packed vector x[d(d+1)/2]
+__device__ __forceinline__ int fill_triangular_src(int d, int f) {
+  const int m = d * (d + 1) / 2;
+  return f < m - d ? d + f : 2 * m - d - 1 - f;
 }
 
 // theta = f(z) for one chain; returns fldj(z)
@@ -148,20 +156,27 @@ __device__ __forceinline__ U4 draw(uint64_t seed, uint64_t step, uint32_t chain,
 }
 
 // host: validate and copy the caller's block list; P / Pu = constrained / unconstrained sizes
-inline int make_blocks(const bvi_param_block* blocks, int n_blocks, Blocks* out, int* P, int* Pu) {
+// (allow_tril: FILL_SCALE_TRIL blocks are implemented by the wave-per-chain kernels only)
+inline int make_blocks(const bvi_param_block* blocks, int n_blocks, Blocks* out, int* P, int* Pu,
+                       bool allow_tril = false) {
   if (!blocks || n_blocks < 1 || n_blocks > BVI_MAX_PARAM_BLOCKS) return BVI_ERR_ARG;
   out->n = n_blocks;
   *P = 0;
   *Pu = 0;
   for (int i = 0; i < n_blocks; ++i) {
     const bvi_param_block b = blocks[i];
-    if (b.size < 1 || b.bijector < BVI_BIJ_IDENTITY || b.bijector > BVI_BIJ_SOFTMAX_CENTERED ||
+    if (b.size < 1 || b.bijector < BVI_BIJ_IDENTITY || b.bijector > BVI_BIJ_FILL_SCALE_TRIL ||
         b.prior < BVI_PRIOR_NONE || b.prior > BVI_PRIOR_DIRICHLET)
       return BVI_ERR_ARG;
     if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED && b.size < 2) return BVI_ERR_ARG;
+    if (b.bijector == BVI_BIJ_FILL_SCALE_TRIL) {
+      if (!allow_tril) return BVI_ERR_UNSUPPORTED;
+      if (b.dim < 1 || b.dim > 1024 || b.size % (b.dim * b.dim) != 0 || b.prior == BVI_PRIOR_DIRICHLET)
+        return BVI_ERR_ARG;
+    }
     out->b[i] = b;
     *P += b.size;
-    *Pu += b.bijector == BVI_BIJ_SOFTMAX_CENTERED ? b.size - 1 : b.size;
+    *Pu += usize_of(b);
   }
   return BVI_OK;
 }

@@ -70,6 +70,9 @@ extern "C" {
 #define BVI_BIJ_SOFTPLUS 1          /* positive parameters (HalfNormal prior)             */
 #define BVI_BIJ_EXP 2
 #define BVI_BIJ_SOFTMAX_CENTERED 3  /* R^{K-1} -> K-simplex (Dirichlet prior)             */
+#define BVI_BIJ_FILL_SCALE_TRIL 4   /* size/(dim*dim) packed vectors [dim(dim+1)/2] -> lower-triangular
+                                       [dim,dim] matrices, softplus(.) + shift on the diagonal
+                                       (tfb.FillScaleTriL: the Cholesky factors of a mixture)      */
 
 /* prior of a parameter block (README.md:114-117, 747-751; mixture notebook cell 15) */
 #define BVI_PRIOR_NONE 0
@@ -85,6 +88,8 @@ typedef struct bvi_param_block {
   int32_t prior;
   float a;
   float b;
+  int32_t dim;   /* FILL_SCALE_TRIL: matrix dimension; 0 otherwise */
+  float shift;   /* FILL_SCALE_TRIL: added to the softplus of the diagonal */
 } bvi_param_block;
 
 int bvi_version(void);
@@ -194,6 +199,49 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
                 float* z, float* grad_z, float* lp, const float* p, const float* z0, const float* g0,
                 const float* lp0, const float* k0, unsigned char* is_accepted, float* log_accept_ratio,
                 void* stream);
+
+/* The two leapfrog halves with one signed step size per chain (step_sizes[C]; 0 leaves a chain untouched):
+ * what the No-U-Turn sampler needs, whose chains integrate forwards or backwards in time and stop at
+ * different tree sizes (transition_kernels.py:238-246). */
+int bvi_leapfrog_pre_chainwise(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* step_sizes,
+                               float* z, float* p, const float* grad_z, float* theta, void* stream);
+int bvi_leapfrog_post_chainwise(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* step_sizes,
+                                const float* z, float* p, float* theta, const float* loglik, float* grad_theta,
+                                float* lp, float* grad_z, void* stream);
+
+/* ---- the No-U-Turn sampler over the batched likelihood kernels: per-chain tree bookkeeping on the device.
+ * Replaces tfp.mcmc.NoUTurnSampler.one_step (bayes_vi/inference/mcmc/transition_kernels.py:238-246) for
+ * datasets too large for bvi_nuts_fused.  All arrays are device memory owned by the caller; [C] = n_chains,
+ * [C,Pu] = n_chains x n_unconstrained.  Sequence of one transition number `step`:
+ *   bvi_nuts_begin;
+ *   for depth = 0 .. max_tree_depth-1:  bvi_nuts_subtree_begin(depth);
+ *     for leaf = 0 .. 2^depth-1:  bvi_leapfrog_pre_chainwise(se, q, p, gq -> theta), <family>_logp_grad(theta)
+ *         [all-reduce over row shards], bvi_leapfrog_post_chainwise(se, q, p, theta, loglik, grad_theta -> lpq, gq),
+ *         bvi_nuts_leaf(leaf, any_building)   -- stop the leaf loop when *any_building stays 0
+ *     bvi_nuts_subtree_end(any_active)        -- stop the depth loop when *any_active stays 0
+ * (the caller zeroes the word before each call that may set it).  Afterwards z, lp, grad hold the new state,
+ * sum_acc / n_leap the mean acceptance statistic, flags the per-chain outcome.  Philox streams as in bvi_nuts_fused. */
+#define BVI_NUTS_ACTIVE 1
+#define BVI_NUTS_BUILDING 2
+#define BVI_NUTS_TURNED 4
+#define BVI_NUTS_DIVERGED 8
+#define BVI_NUTS_MOVED 16
+#define BVI_NUTS_FORWARD 32
+typedef struct bvi_nuts_state {
+  int n_chains, n_unconstrained, max_tree_depth;
+  float step_size, max_energy_diff;
+  float *z, *lp, *grad;                 /* current sample [C,Pu], its log density [C] and gradient [C,Pu]: in/out */
+  float *q, *p, *gq, *lpq;              /* cursor of the subtree under construction [C,Pu] x3, [C] */
+  float *ql, *pl, *gl, *qr, *pr, *gr;   /* trajectory ends [C,Pu] */
+  float *sub_q, *sub_g, *sub_lp;        /* candidate of the subtree [C,Pu] x2, [C] */
+  float *ck_q, *ck_p;                   /* U-turn checkpoints [max_tree_depth+1, C, Pu] */
+  float *h0, *log_w, *sub_log_w, *sum_acc, *log_u_sub, *se;   /* [C]; se = signed step size of this subtree, 0 = frozen */
+  int *n_leap, *leaf_ctr, *flags;       /* [C]; flags = OR of BVI_NUTS_* */
+} bvi_nuts_state;
+int bvi_nuts_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, void* stream);
+int bvi_nuts_subtree_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, int depth, void* stream);
+int bvi_nuts_leaf(const bvi_nuts_state* state, uint64_t seed, uint64_t step, int leaf, int* any_building, void* stream);
+int bvi_nuts_subtree_end(const bvi_nuts_state* state, int* any_active, void* stream);
 
 /* Whole HMC transitions in one launch, for datasets small enough that one workgroup per chain can
  * re-stream them at every leapfrog step (tens to ~10^5 rows): per transition a Philox momentum draw,

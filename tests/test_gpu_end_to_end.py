@@ -451,6 +451,85 @@ def test_fused_nuts_kernel_follows_oracle_transition_by_transition(bvi, gpu_devi
         assert compared > 0.6 * c * T, (name, compared)
 
 
+def test_batched_device_nuts_follows_oracle_transition_by_transition(bvi, gpu_device):
+    """The NUTS built from bvi_nuts_begin / subtree_begin / leaf / subtree_end + the chain-wise leapfrog
+    halves + the batched likelihood kernels, against oracle/nuts.py with the same Philox numbers: chains
+    advance in lock-step with frozen chains masked on the device, and every chain must still reproduce
+    its own tree, move decision and new position."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import BatchedDeviceNoUTurnSamplerKernel
+    from oracle import nuts
+    rng = np.random.default_rng(32)
+    for name, model, ds, spec, z in _fused_cases(bvi, rng):
+        post = bvi.MCMC(model, ds).posterior
+        z = z.astype(np.float32)[:5]
+        c, pu = z.shape
+        eps = {'normal': 0.2, 'linreg': 0.01, 'gmm1d': 0.04}[name]
+        kern = BatchedDeviceNoUTurnSamplerKernel(post, step_size=eps, max_tree_depth=4, seed=9)
+        zt = torch.tensor(z, device=gpu_device)
+        st = kern.bootstrap(zt)
+        T = 25
+        f = lambda q: spec.log_post_unconstrained(q)
+        compared, sizes = 0, set()
+        for t in range(T):
+            prev = zt.cpu().numpy().astype(np.float64)
+            zt, st, tr = kern.one_step(zt, st)
+            znew = zt.cpu().numpy()
+            leaps = tr['leapfrogs_taken'].cpu().numpy(); moved = tr['is_accepted'].cpu().numpy()
+            lrs = tr['log_accept_ratio'].cpu().numpy()
+            assert not tr['has_divergence'].any()
+            lp_new, g_new = f(znew.astype(np.float64))
+            # the cached log density / gradient travel with the position
+            np.testing.assert_allclose(st['target_log_prob'].cpu().numpy(), lp_new, rtol=2e-5, atol=2e-3)
+            for ch in range(c):
+                lp0, g0 = f(prev[ch][None])
+                out = nuts.nuts_step(f, prev[ch], float(lp0[0]), g0[0], chain=ch, seed=9, step=t, step_size=eps,
+                                     max_tree_depth=4)
+                if out['margin'] > 2e-3:
+                    assert out['leapfrogs'] == leaps[ch], (name, ch, t)
+                    assert out['moved'] == bool(moved[ch]), (name, ch, t)
+                    np.testing.assert_allclose(znew[ch], out['z'], rtol=2e-4, atol=2e-4)
+                    assert abs(lrs[ch] - out['log_accept_ratio']) < 5e-3
+                    compared += 1
+                    sizes.add(int(leaps[ch]))
+        assert compared > 0.6 * c * T, (name, compared)
+        assert len(sizes) >= 2, (name, sizes)      # chains did stop at different tree sizes
+
+
+def test_batched_device_nuts_through_mcmc_fit_on_a_large_regression(bvi, gpu_device):
+    """A regression too large for the one-workgroup-per-chain kernel: MCMC.fit selects the batched device
+    NUTS; posterior moments against the exact conjugate answer (flat-ish priors, known noise scale is
+    not assumed: compare the weights with ordinary least squares, whose sampling sd is sigma/sqrt(N))."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import BatchedDeviceNoUTurnSamplerKernel
+    rng = np.random.default_rng(8)
+    n, d = 100000, 3
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    w_true, b_true, sig = np.array([0.7, -1.2, 0.4]), 0.3, 0.8
+    y = (X @ w_true + b_true + sig * rng.normal(size=n)).astype(np.float32)
+    priors = collections.OrderedDict(b=bvi.tfd.Normal(0., 10.), w=bvi.tfd.Normal(torch.zeros(d), 10.),
+                                     scale=bvi.tfd.HalfNormal(10.))
+    model = bvi.Model(priors, lambda b, w, scale, features: bvi.tfd.Normal(loc=b + bvi.symbolic.matvec(features, w),
+                                                                           scale=scale))
+    df = pd.DataFrame(X, columns=['f%d' % i for i in range(d)]); df['y'] = y
+    ds = bvi.make_dataset_from_df(df, ['y'], ['f%d' % i for i in range(d)], format_features_as='tensor')
+    cfg = bvi.NoUTurnSampler(step_size=0.002, max_tree_depth=5,
+                             stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(num_adaptation_steps=150))
+    mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=cfg)
+    kernel, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
+    assert isinstance(kernel.inner, BatchedDeviceNoUTurnSamplerKernel)
+    A = np.concatenate([X.astype(np.float64), np.ones((n, 1))], 1)
+    ols = np.linalg.lstsq(A, y.astype(np.float64), rcond=None)[0]
+    init = [torch.full((4,), float(ols[d])), torch.tensor(np.tile(ols[:d], (4, 1)), dtype=torch.float32),
+            torch.full((4,), 1.0)]
+    res = mcmc.fit(initial_state=init, num_samples=300, num_burnin_steps=200, progress_bar=False, seed=2)
+    ws = res.samples[1].cpu().numpy().reshape(-1, d)
+    sd = sig / math.sqrt(n)
+    assert np.abs(ws.mean(0) - ols[:d]).max() < 6 * sd / math.sqrt(300 * 4 / 2) + 0.3 * sd
+    assert ws.std(0) == pytest.approx(np.full(d, sd), rel=0.25)
+    scale = res.samples[-1].cpu().numpy()
+    assert scale.mean() == pytest.approx(sig, rel=0.02)
+    assert not bool(res.trace['has_divergence'].any())
+
+
 def test_fused_nuts_through_mcmc_fit(bvi):
     """BASELINE configs[0] through MCMC.fit: the driver selects the fused NUTS kernel; dual averaging runs
     transition by transition during adaptation, the remaining burn-in and all samples are one launch each."""
@@ -493,8 +572,14 @@ def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
         constraining_bijectors=[tfb.SoftmaxCentered(), tfb.Identity(), tfb.FillScaleTriL(d, 1e-3, batch=k)])
     df = pd.DataFrame(Y, columns=['y%d' % i for i in range(d)])
     ds = bvi.make_dataset_from_df(df, target_names=list(df.columns))
-    mc = bvi.MCMC(model, ds, bvi.NoUTurnSampler(step_size=0.02, max_tree_depth=4))
+    cfg = bvi.NoUTurnSampler(step_size=0.02, max_tree_depth=4)
+    mc = bvi.MCMC(model, ds, cfg)
     post = mc.posterior
+    # the Cholesky-factor bijector is one of the device-side blocks, so assembly and NUTS stay on the stream
+    from bayes_vi_amd.inference.mcmc.device_hmc import BatchedDeviceNoUTurnSamplerKernel
+    assert post.device_blocks() is not None
+    made = cfg(post.unconstrained_log_prob_and_grad)[0]
+    assert isinstance(getattr(made, 'inner', made), BatchedDeviceNoUTurnSamplerKernel)
     pu = model.flat_unconstrained_param_event_ndims
     assert pu == (k - 1) + k * d + k * m
     z = np.concatenate([rng.normal(0, .2, (c, k - 1)), true_mu.reshape(1, -1) + rng.normal(0, .2, (c, k * d)),
