@@ -302,18 +302,31 @@ __global__ void fullcov_colstats(const float* __restrict__ Y, int64_t n, int D, 
   }
 }
 
-// stage 2: center[d] = mean, cscale[d] = power-of-two scale of max |y - mean| (0 for a constant / unused column)
-__global__ void fullcov_colstats_final(const double* __restrict__ psum, const float* __restrict__ pmin,
-                                       const float* __restrict__ pmax, int nblk, int64_t n, int D,
-                                       float* __restrict__ center, float* __restrict__ cscale) {
-  const int col = threadIdx.x;
-  if (col >= DP) return;
+// stage 2 (one workgroup of 256 threads = 8 groups x DP columns, each group folds every 8th partial):
+// center[d] = mean, cscale[d] = power-of-two scale of max |y - mean| (0 for a constant / unused column)
+__global__ __launch_bounds__(256) void fullcov_colstats_final(const double* __restrict__ psum,
+                                                              const float* __restrict__ pmin,
+                                                              const float* __restrict__ pmax, int nblk, int64_t n,
+                                                              int D, float* __restrict__ center,
+                                                              float* __restrict__ cscale) {
+  static_assert(DP == 32, "8 groups x 32 columns");
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   double sum = 0.0;
   float mn = INFINITY, mx = -INFINITY;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = grp; b < nblk; b += 8) {
     sum += psum[b * DP + col];
     mn = fminf(mn, pmin[b * DP + col]);
     mx = fmaxf(mx, pmax[b * DP + col]);
+  }
+  __shared__ double ssum[8][DP];
+  __shared__ float smn[8][DP], smx[8][DP];
+  ssum[grp][col] = sum; smn[grp][col] = mn; smx[grp][col] = mx;
+  __syncthreads();
+  if (grp != 0) return;
+  for (int q = 1; q < 8; ++q) {
+    sum += ssum[q][col];
+    mn = fminf(mn, smn[q][col]);
+    mx = fmaxf(mx, smx[q][col]);
   }
   float m = 0.f, sc = 0.f;
   if (col < D && n > 0) {
@@ -570,50 +583,54 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
-// one block of DP threads per (chain, component); thread j owns column j / entry j
-__global__ void fullcov_finalize(const float* __restrict__ partials, int nb, int64_t n, int D, int K,
-                                 const float* __restrict__ theta, const float* __restrict__ Ainv, int C,
-                                 float* __restrict__ logp, float* __restrict__ grad) {
-  constexpr int Q = 1 + DP + DP * DP;
-  const int c = blockIdx.x / K, k = blockIdx.x % K, j = threadIdx.x;
+// one block of 8 x DP threads per (chain, component): thread (j, ig) owns column j of the rows i = ig, ig + 8, ...
+__global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restrict__ partials, int nb, int64_t n,
+                                                           int D, int K, const float* __restrict__ theta,
+                                                           const float* __restrict__ Ainv, int C,
+                                                           float* __restrict__ logp, float* __restrict__ grad) {
+  constexpr int Q = 1 + DP + DP * DP, RG = DP / 8;
+  const int c = blockIdx.x / K, k = blockIdx.x % K, j = threadIdx.x & (DP - 1), ig = threadIdx.x / DP;
   const int P = K + K * D + K * D * D;
   const int64_t stride = (int64_t)K * Q + 1;
   __shared__ double S2[DP][DP + 1], S1[DP], S0s, A[DP][DP + 1];
   double s1 = 0.0, s0 = 0.0, lp = 0.0;
-  double col[DP];
-  for (int i = 0; i < DP; ++i) col[i] = 0.0;
+  double col[RG];
+  for (int r = 0; r < RG; ++r) col[r] = 0.0;
   for (int b = 0; b < nb; ++b) {
     const float* p = partials + ((int64_t)b * C + c) * stride + (int64_t)k * Q;
-    s1 += (double)p[1 + j];
-    for (int i = 0; i < DP; ++i) col[i] += (double)p[1 + DP + i * DP + j];
-    if (j == 0) {
+    for (int r = 0; r < RG; ++r) col[r] += (double)p[1 + DP + (ig + 8 * r) * DP + j];
+    if (ig == 0) s1 += (double)p[1 + j];
+    if (threadIdx.x == 0) {
       s0 += (double)p[0];
       if (k == 0) lp += (double)partials[((int64_t)b * C + c) * stride + (int64_t)K * Q];
     }
   }
-  for (int i = 0; i < DP; ++i) {
-    S2[i][j] = col[i];
+  for (int r = 0; r < RG; ++r) {
+    const int i = ig + 8 * r;
+    S2[i][j] = col[r];
     A[i][j] = (double)Ainv[((int64_t)c * K + k) * DP * DP + i * DP + j];
   }
-  S1[j] = s1;
-  if (j == 0) S0s = s0;
+  if (ig == 0) S1[j] = s1;
+  if (threadIdx.x == 0) S0s = s0;
   __syncthreads();
-  if (j == 0 && k == 0) logp[c] = (float)lp;
+  if (threadIdx.x == 0 && k == 0) logp[c] = (float)lp;
   if (!grad) return;
   const float* th = theta + (int64_t)c * P;
   float* gc = grad + (int64_t)c * P;
-  if (j == 0) {
+  if (threadIdx.x == 0) {
     double wsum = 0.0;
     for (int m = 0; m < K; ++m) wsum += (double)th[m];
     gc[k] = (float)(S0s / (double)th[k] - (double)n / wsum);
   }
   if (j < D) {
     // d/dmu_j = sum_m A[m][j] S1[m];  d/dL[i][j] (i >= j) = sum_m A[m][i] S2[m][j] - S0 [i == j] / L_jj
-    double gm = 0.0;
-    for (int m = 0; m < D; ++m) gm += A[m][j] * S1[m];
-    gc[K + k * D + j] = (float)gm;
+    if (ig == 0) {
+      double gm = 0.0;
+      for (int m = 0; m < D; ++m) gm += A[m][j] * S1[m];
+      gc[K + k * D + j] = (float)gm;
+    }
     const float* L = th + K + K * D + k * D * D;
-    for (int i = 0; i < D; ++i) {
+    for (int i = ig; i < D; i += 8) {
       double v = 0.0;
       if (i >= j) {
         for (int m = 0; m < D; ++m) v += A[m][i] * S2[m][j];
@@ -685,7 +702,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
 #undef BVI_FC_CASE
   } else {
     hipLaunchKernelGGL(fullcov_colstats, dim3(kStatBlocks), dim3(256), 0, s, Y, n, d, psum, pmin, pmax);
-    hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(64), 0, s, (const double*)psum, (const float*)pmin,
+    hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(256), 0, s, (const double*)psum, (const float*)pmin,
                        (const float*)pmax, kStatBlocks, n, d, center, cscale);
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
                        bvec, blo, cst);
@@ -700,7 +717,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
                          partials);
   }
   BVI_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(DP), 0, s, (const float*)partials, nb, n, d, k, theta,
+  hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(8 * DP), 0, s, (const float*)partials, nb, n, d, k, theta,
                      (const float*)Ainv, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;

@@ -3,7 +3,7 @@
 // tfp.mcmc.NoUTurnSampler (bayes_vi/inference/mcmc/transition_kernels.py:238-246) -- direction and
 // subtree set-up, energy and divergence test, multinomial sampling inside the subtree, checkpointed
 // U-turn checks, biased progressive sampling between subtrees, the stopping rule -- runs on the device,
-// one wave per chain, lanes over the parameter elements.  The host only sequences the launches
+// one workgroup per chain (64 to 1024 threads, by the size of the parameter vector), threads over its elements.  The host only sequences the launches
 //   begin; per depth { subtree_begin; per leaf { leapfrog_pre_chainwise, <family>_logp_grad
 //   [, all-reduce], leapfrog_post_chainwise, leaf }; subtree_end }
 // and reads one word per leaf / depth to learn whether any chain is still building / still active.
@@ -19,34 +19,32 @@ namespace {
 
 enum : int { F_ACTIVE = 1, F_SUB_OK = 2, F_TURN = 4, F_DIVERGED = 8, F_MOVED = 16, F_RIGHT = 32 };
 
-__device__ __forceinline__ float nb_wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 __device__ __forceinline__ float nb_log_add_exp(float a, float b) {
   const float m = fmaxf(a, b);
   if (m == -INFINITY) return -INFINITY;
   return m + logf(expf(a - m) + expf(b - m));
 }
 
-// (b_q - a_q) . a_p <= 0 or (b_q - a_q) . b_p <= 0, vectors of one chain, all lanes of the wave take part
-__device__ __forceinline__ bool nb_turning(const float* aq, const float* ap, const float* bq, const float* bp, int Pu) {
+// (b_q - a_q) . a_p <= 0 or (b_q - a_q) . b_p <= 0, vectors of one chain, all threads of the workgroup take part
+__device__ __forceinline__ bool nb_turning(const float* aq, const float* ap, const float* bq, const float* bp, int Pu,
+                                           float* red) {
   float d1 = 0.f, d2 = 0.f;
-  for (int j = threadIdx.x & 63; j < Pu; j += 64) {
+  for (int j = threadIdx.x; j < Pu; j += blockDim.x) {
     const float dq = bq[j] - aq[j];
     d1 = fmaf(dq, ap[j], d1);
     d2 = fmaf(dq, bp[j], d2);
   }
-  return nb_wave_sum(d1) <= 0.f || nb_wave_sum(d2) <= 0.f;
+  d1 = block_reduce<false>(d1, red);
+  d2 = block_reduce<false>(d2, red);
+  return d1 <= 0.f || d2 <= 0.f;
 }
 
-__global__ __launch_bounds__(64) void nuts_begin_kernel(bvi_nuts_state s, uint64_t seed, uint64_t step) {
-  const int c = blockIdx.x, lane = threadIdx.x, Pu = s.n_unconstrained;
+__global__ __launch_bounds__(1024) void nuts_begin_kernel(bvi_nuts_state s, uint64_t seed, uint64_t step) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, lane = threadIdx.x, nt = blockDim.x, Pu = s.n_unconstrained;
   const int64_t o = (int64_t)c * Pu;
   float ke = 0.f;
-  for (int j = lane; j < Pu; j += 64) {
+  for (int j = lane; j < Pu; j += nt) {
     float v[4];
     normal4(draw(seed, step, c, j >> 2, 0), v);
     const float p0 = v[j & 3];
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(64) void nuts_begin_kernel(bvi_nuts_state s, uint64
     s.ql[o + j] = s.z[o + j]; s.qr[o + j] = s.z[o + j];
     s.gl[o + j] = s.grad[o + j]; s.gr[o + j] = s.grad[o + j];
   }
-  ke = nb_wave_sum(ke);
+  ke = block_reduce<false>(ke, red);
   if (lane == 0) {
     s.h0[c] = -s.lp[c] + ke;
     s.log_w[c] = 0.f;
@@ -66,16 +64,16 @@ __global__ __launch_bounds__(64) void nuts_begin_kernel(bvi_nuts_state s, uint64
   }
 }
 
-__global__ __launch_bounds__(64) void nuts_subtree_begin_kernel(bvi_nuts_state s, uint64_t seed, uint64_t step,
+__global__ __launch_bounds__(1024) void nuts_subtree_begin_kernel(bvi_nuts_state s, uint64_t seed, uint64_t step,
                                                                 int depth) {
-  const int c = blockIdx.x, lane = threadIdx.x, Pu = s.n_unconstrained;
+  const int c = blockIdx.x, lane = threadIdx.x, nt = blockDim.x, Pu = s.n_unconstrained;
   const int64_t o = (int64_t)c * Pu;
   const int fl = s.flags[c];
   const bool active = fl & F_ACTIVE;
   const U4 rd = draw(seed, step, c, depth, 2);
   const bool go_right = u01(rd.x) < 0.5f;
   if (active) {
-    for (int j = lane; j < Pu; j += 64) {
+    for (int j = lane; j < Pu; j += nt) {
       s.q[o + j] = go_right ? s.qr[o + j] : s.ql[o + j];
       s.p[o + j] = go_right ? s.pr[o + j] : s.pl[o + j];
       s.gq[o + j] = go_right ? s.gr[o + j] : s.gl[o + j];
@@ -83,6 +81,7 @@ __global__ __launch_bounds__(64) void nuts_subtree_begin_kernel(bvi_nuts_state s
       s.sub_g[o + j] = s.grad[o + j];
     }
   }
+  __syncthreads();                          // every thread has read the chain's scalars
   if (lane == 0) {
     s.se[c] = active ? (go_right ? s.step_size : -s.step_size) : 0.f;
     s.log_u_sub[c] = logf(u01(rd.y));
@@ -94,16 +93,17 @@ __global__ __launch_bounds__(64) void nuts_subtree_begin_kernel(bvi_nuts_state s
 
 // after leapfrog_post_chainwise: the cursor (q, p, gq, lpq) is one leapfrog step further for every chain
 // that is still building its subtree
-__global__ __launch_bounds__(64) void nuts_leaf_kernel(bvi_nuts_state s, uint64_t seed, uint64_t step, int leaf,
+__global__ __launch_bounds__(1024) void nuts_leaf_kernel(bvi_nuts_state s, uint64_t seed, uint64_t step, int leaf,
                                                        int* __restrict__ any_building) {
-  const int c = blockIdx.x, lane = threadIdx.x, Pu = s.n_unconstrained, C = s.n_chains;
+  __shared__ float red[16];
+  const int c = blockIdx.x, lane = threadIdx.x, nt = blockDim.x, Pu = s.n_unconstrained, C = s.n_chains;
   const int64_t o = (int64_t)c * Pu;
   int fl = s.flags[c];
   if (!(fl & F_SUB_OK)) return;
   const bool go_right = fl & F_RIGHT;
   float ke = 0.f;
-  for (int j = lane; j < Pu; j += 64) ke = fmaf(0.5f * s.p[o + j], s.p[o + j], ke);
-  ke = nb_wave_sum(ke);
+  for (int j = lane; j < Pu; j += nt) ke = fmaf(0.5f * s.p[o + j], s.p[o + j], ke);
+  ke = block_reduce<false>(ke, red);
   const float lpq = s.lpq[c];
   float dh = (-lpq + ke) - s.h0[c];
   if (!isfinite(dh)) dh = INFINITY;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void nuts_leaf_kernel(bvi_nuts_state s, uint64_
   const int ctr = s.leaf_ctr[c];
   const float log_ul = logf(u01(draw(seed, step, c, ctr, 3).x));
   if (ok && log_ul < lw - new_w) {          // multinomial sample within the subtree
-    for (int j = lane; j < Pu; j += 64) {
+    for (int j = lane; j < Pu; j += nt) {
       s.sub_q[o + j] = s.q[o + j];
       s.sub_g[o + j] = s.gq[o + j];
     }
@@ -125,17 +125,18 @@ __global__ __launch_bounds__(64) void nuts_leaf_kernel(bvi_nuts_state s, uint64_
   if ((leaf & 1) == 0) {
     float* cq = s.ck_q + ((int64_t)hi * C + c) * Pu;
     float* cp = s.ck_p + ((int64_t)hi * C + c) * Pu;
-    for (int j = lane; j < Pu; j += 64) { cq[j] = s.q[o + j]; cp[j] = s.p[o + j]; }
+    for (int j = lane; j < Pu; j += nt) { cq[j] = s.q[o + j]; cp[j] = s.p[o + j]; }
   } else {
     const int lo = hi - (__ffs(~leaf) - 1) + 1;
     for (int k = lo; k <= hi; ++k) {
       const float* cq = s.ck_q + ((int64_t)k * C + c) * Pu;
       const float* cp = s.ck_p + ((int64_t)k * C + c) * Pu;
-      const bool tn = go_right ? nb_turning(cq, cp, s.q + o, s.p + o, Pu) : nb_turning(s.q + o, s.p + o, cq, cp, Pu);
+      const bool tn = go_right ? nb_turning(cq, cp, s.q + o, s.p + o, Pu, red) : nb_turning(s.q + o, s.p + o, cq, cp, Pu, red);
       turn |= ok && tn;
     }
   }
   const bool sub_ok = ok && !turn;
+  __syncthreads();                          // every thread has read the chain's scalars
   if (lane == 0) {
     s.n_leap[c] += 1;
     s.leaf_ctr[c] = ctr + 1;
@@ -148,13 +149,14 @@ __global__ __launch_bounds__(64) void nuts_leaf_kernel(bvi_nuts_state s, uint64_
   }
 }
 
-__global__ __launch_bounds__(64) void nuts_subtree_end_kernel(bvi_nuts_state s, int* __restrict__ any_active) {
-  const int c = blockIdx.x, lane = threadIdx.x, Pu = s.n_unconstrained;
+__global__ __launch_bounds__(1024) void nuts_subtree_end_kernel(bvi_nuts_state s, int* __restrict__ any_active) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, lane = threadIdx.x, nt = blockDim.x, Pu = s.n_unconstrained;
   const int64_t o = (int64_t)c * Pu;
   int fl = s.flags[c];
   if (!(fl & F_ACTIVE)) return;
   const bool go_right = fl & F_RIGHT;
-  for (int j = lane; j < Pu; j += 64) {     // the trajectory end moves to where the subtree stopped
+  for (int j = lane; j < Pu; j += nt) {     // the trajectory end moves to where the subtree stopped
     if (go_right) { s.qr[o + j] = s.q[o + j]; s.pr[o + j] = s.p[o + j]; s.gr[o + j] = s.gq[o + j]; }
     else { s.ql[o + j] = s.q[o + j]; s.pl[o + j] = s.p[o + j]; s.gl[o + j] = s.gq[o + j]; }
   }
@@ -162,10 +164,10 @@ __global__ __launch_bounds__(64) void nuts_subtree_end_kernel(bvi_nuts_state s, 
   const float log_w = s.log_w[c], sub_w = s.sub_log_w[c];
   const bool accept = complete && s.log_u_sub[c] < sub_w - log_w;     // biased progressive sampling
   if (accept) {
-    for (int j = lane; j < Pu; j += 64) { s.z[o + j] = s.sub_q[o + j]; s.grad[o + j] = s.sub_g[o + j]; }
+    for (int j = lane; j < Pu; j += nt) { s.z[o + j] = s.sub_q[o + j]; s.grad[o + j] = s.sub_g[o + j]; }
   }
   __syncthreads();                          // the end points written above are read back by other lanes below
-  const bool turning = nb_turning(s.ql + o, s.pl + o, s.qr + o, s.pr + o, Pu);
+  const bool turning = nb_turning(s.ql + o, s.pl + o, s.qr + o, s.pr + o, Pu, red);
   const bool active = complete && !turning;
   if (lane == 0) {
     if (accept) s.lp[c] = s.sub_lp[c];
@@ -196,7 +198,7 @@ extern "C" {
 int bvi_nuts_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, void* stream) {
   const int st = check_state(state);
   if (st != BVI_OK) return st;
-  hipLaunchKernelGGL(nuts_begin_kernel, dim3(state->n_chains), dim3(64), 0, (hipStream_t)stream, *state, seed, step);
+  hipLaunchKernelGGL(nuts_begin_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state, seed, step);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
@@ -205,7 +207,7 @@ int bvi_nuts_subtree_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t 
   const int st = check_state(state);
   if (st != BVI_OK) return st;
   if (depth < 0 || depth >= state->max_tree_depth) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(nuts_subtree_begin_kernel, dim3(state->n_chains), dim3(64), 0, (hipStream_t)stream, *state, seed,
+  hipLaunchKernelGGL(nuts_subtree_begin_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state, seed,
                      step, depth);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -216,7 +218,7 @@ int bvi_nuts_leaf(const bvi_nuts_state* state, uint64_t seed, uint64_t step, int
   const int st = check_state(state);
   if (st != BVI_OK) return st;
   if (leaf < 0 || !any_building) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(nuts_leaf_kernel, dim3(state->n_chains), dim3(64), 0, (hipStream_t)stream, *state, seed, step,
+  hipLaunchKernelGGL(nuts_leaf_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state, seed, step,
                      leaf, any_building);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -226,7 +228,7 @@ int bvi_nuts_subtree_end(const bvi_nuts_state* state, int* any_active, void* str
   const int st = check_state(state);
   if (st != BVI_OK) return st;
   if (!any_active) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(nuts_subtree_end_kernel, dim3(state->n_chains), dim3(64), 0, (hipStream_t)stream, *state,
+  hipLaunchKernelGGL(nuts_subtree_end_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state,
                      any_active);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;

@@ -12,8 +12,9 @@
 // (seed; step, chain, element): every rank of a row-sharded run draws the same
 // numbers, so replicated chains need no broadcast.
 //
-// One thread per chain; parameter vectors are tiny ([C, P] with P <= a few hundred)
-// and stay resident in device memory between the launches of a trajectory.
+// One workgroup per chain (64 threads for the usual handful of parameters, up to 1024 for the tens of
+// thousands of a full-covariance mixture); the [C, P] vectors stay resident in device memory between
+// the launches of a trajectory.
 #include "bvi_common.h"
 #include "posterior_device.h"
 
@@ -37,18 +38,7 @@ __global__ void philox_normal_kernel(uint64_t seed, uint64_t step, int C, int P,
   }
 }
 
-// ---- posterior assembly: one wave per chain, lanes stride over the parameter elements ----
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max64(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
+// ---- posterior assembly: one workgroup per chain, threads stride over the parameter elements ----
 // log prior of one element and its score
 __device__ __forceinline__ float prior_elem(const bvi_param_block& b, int j, float th, float* score) {
   if (b.prior == BVI_PRIOR_NORMAL) {
@@ -69,7 +59,7 @@ __device__ __forceinline__ float prior_elem(const bvi_param_block& b, int j, flo
   return 0.f;
 }
 
-// The work of one chain (one wave).  PRE: the position the constraint is applied to is
+// The work of one chain (one workgroup; `red` = __shared__ float[16] for its reductions).  PRE: the position the constraint is applied to is
 // z + eps (p + eps/2 g), formed on the fly from the old z, p, g (which are updated in place afterwards).
 // ASSEMBLE: also priors, fldj, chain rule (gl gets the prior score added in place, gz is written);
 // HALFSTEP: then p += eps/2 gz.  Every in-place update is made by the lane that owns the element,
@@ -77,8 +67,9 @@ __device__ __forceinline__ float prior_elem(const bvi_param_block& b, int j, flo
 template <bool PRE, bool ASSEMBLE, bool HALFSTEP>
 __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __restrict__ z, float* __restrict__ p,
                            const float* __restrict__ g_old, float* __restrict__ theta, const float* __restrict__ ll,
-                           float* __restrict__ gl, float* __restrict__ lp, float* __restrict__ gz, int c) {
-  const int lane = threadIdx.x & 63;
+                           float* __restrict__ gl, float* __restrict__ lp, float* __restrict__ gz, int c,
+                           float* red) {
+  const int lane = threadIdx.x, nt = blockDim.x;
   auto zval = [&](int i) -> float {
     if (PRE) return fmaf(eps, fmaf(0.5f * eps, g_old[i], p[i]), z[i]);
     return z[i];
@@ -89,13 +80,13 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
     const bvi_param_block b = bl.b[i];
     if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED) {
       float m = 0.f;     // the appended logit is 0
-      for (int j = lane; j < b.size - 1; j += 64) m = fmaxf(m, zval(oz + j));
-      m = wave_max64(m);
+      for (int j = lane; j < b.size - 1; j += nt) m = fmaxf(m, zval(oz + j));
+      m = block_reduce<true>(m, red);
       float sp = 0.f;
-      for (int j = lane; j < b.size - 1; j += 64) sp += expf(zval(oz + j) - m);
-      const float lse = m + logf(expf(-m) + wave_sum64(sp));
+      for (int j = lane; j < b.size - 1; j += nt) sp += expf(zval(oz + j) - m);
+      const float lse = m + logf(expf(-m) + block_reduce<false>(sp, red));
       float inner_p = 0.f;
-      for (int j = lane; j < b.size; j += 64) {
+      for (int j = lane; j < b.size; j += nt) {
         const float ly = (j < b.size - 1 ? zval(oz + j) : 0.f) - lse;
         const float th = expf(ly);
         theta[ot + j] = th;
@@ -110,8 +101,8 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
         }
       }
       if (ASSEMBLE && gl && gz) {
-        const float inner = wave_sum64(inner_p);
-        for (int j = lane; j < b.size - 1; j += 64) {
+        const float inner = block_reduce<false>(inner_p, red);
+        for (int j = lane; j < b.size - 1; j += nt) {
           const float th = expf(zval(oz + j) - lse);
           const float gzj = th * (gl[ot + j] - inner) + 1.f - (float)b.size * th;
           gz[oz + j] = gzj;
@@ -120,7 +111,7 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
       }
       if (PRE) {
         __syncthreads();   // every lane has read the old z, p of this block; now update them in place
-        for (int j = lane; j < b.size - 1; j += 64) {
+        for (int j = lane; j < b.size - 1; j += nt) {
           const float pj = fmaf(0.5f * eps, g_old[oz + j], p[oz + j]);
           p[oz + j] = pj;
           z[oz + j] = fmaf(eps, pj, z[oz + j]);
@@ -130,7 +121,7 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
       // lanes stride over the constrained entries; every lower-triangular entry reads (and, in place,
       // updates) its own packed element, entries above the diagonal are structural zeros
       const int d = b.dim, dd = d * d, m = d * (d + 1) / 2;
-      for (int t = lane; t < b.size; t += 64) {
+      for (int t = lane; t < b.size; t += nt) {
         const int mat = t / dd, f = t - mat * dd, i = f / d, j = f - i * d;
         float th = 0.f, fl = 0.f, dth = 1.f, dfl = 0.f, x = 0.f;
         const int src = oz + mat * m + fill_triangular_src(d, f);
@@ -162,7 +153,7 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
         }
       }
     } else {
-      for (int j = lane; j < b.size; j += 64) {
+      for (int j = lane; j < b.size; j += nt) {
         const float x = zval(oz + j);
         float th, fl = 0.f, dth = 1.f, dfl = 0.f;   // theta, fldj share, d theta / dx, d fldj / dx
         if (b.bijector == BVI_BIJ_SOFTPLUS) {
@@ -197,74 +188,80 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
     ot += b.size;
   }
   if (ASSEMBLE) {
-    part = wave_sum64(part);
+    part = block_reduce<false>(part, red);
     if (lane == 0) lp[c] = ll[c] + part;
   }
 }
 
 // theta = f(z)
-__global__ __launch_bounds__(64) void constrain_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
+__global__ __launch_bounds__(1024) void constrain_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
                                                        float* __restrict__ theta) {
   const int c = blockIdx.x;
+  __shared__ float red[16];
   chain_work<false, false, false>(bl, P, Pu, 0.f, const_cast<float*>(z) + (int64_t)c * Pu, nullptr, nullptr,
-                                  theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c);
+                                  theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c, red);
 }
 
 // lp = ll + log prior(theta) + fldj(z); gz = chain rule of (gl + grad prior); gl is overwritten
-__global__ __launch_bounds__(64) void assemble_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
+__global__ __launch_bounds__(1024) void assemble_kernel(Blocks bl, int C, int P, int Pu, const float* __restrict__ z,
                                                       float* __restrict__ theta, const float* __restrict__ ll,
                                                       float* __restrict__ gl, float* __restrict__ lp,
                                                       float* __restrict__ gz) {
   const int c = blockIdx.x;
+  __shared__ float red[16];
   chain_work<false, true, false>(bl, P, Pu, 0.f, const_cast<float*>(z) + (int64_t)c * Pu, nullptr, nullptr,
                                  theta + (int64_t)c * P, ll, gl ? gl + (int64_t)c * P : nullptr, lp,
-                                 gz ? gz + (int64_t)c * Pu : nullptr, c);
+                                 gz ? gz + (int64_t)c * Pu : nullptr, c, red);
 }
 
 // leapfrog "pre": p += eps/2 g; z += eps p; theta = f(z)
-__global__ __launch_bounds__(64) void leapfrog_pre_kernel(Blocks bl, int C, int P, int Pu, float eps,
+__global__ __launch_bounds__(1024) void leapfrog_pre_kernel(Blocks bl, int C, int P, int Pu, float eps,
                                                           const float* __restrict__ eps_chain,
                                                           float* __restrict__ z, float* __restrict__ p,
                                                           const float* __restrict__ g, float* __restrict__ theta) {
   const int c = blockIdx.x;
+  __shared__ float red[16];
   if (eps_chain) {
     eps = eps_chain[c];                   // per-chain signed step; 0 = frozen chain: only theta = f(z) is rewritten
     if (eps == 0.f) {
       chain_work<false, false, false>(bl, P, Pu, 0.f, z + (int64_t)c * Pu, nullptr, nullptr, theta + (int64_t)c * P,
-                                      nullptr, nullptr, nullptr, nullptr, c);
+                                      nullptr, nullptr, nullptr, nullptr, c, red);
       return;
     }
   }
   chain_work<true, false, false>(bl, P, Pu, eps, z + (int64_t)c * Pu, p + (int64_t)c * Pu, g + (int64_t)c * Pu,
-                                 theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c);
+                                 theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c, red);
 }
 
 // leapfrog "post": assemble lp, g at the new z, then p += eps/2 g
-__global__ __launch_bounds__(64) void leapfrog_post_kernel(Blocks bl, int C, int P, int Pu, float eps,
+__global__ __launch_bounds__(1024) void leapfrog_post_kernel(Blocks bl, int C, int P, int Pu, float eps,
                                                            const float* __restrict__ eps_chain,
                                                            const float* __restrict__ z, float* __restrict__ p,
                                                            float* __restrict__ theta, const float* __restrict__ ll,
                                                            float* __restrict__ gl, float* __restrict__ lp,
                                                            float* __restrict__ g) {
   const int c = blockIdx.x;
+  __shared__ float red[16];
   if (eps_chain) {
     eps = eps_chain[c];
     if (eps == 0.f) return;               // frozen chain: momentum, log density and gradient stay as they are
   }
   chain_work<false, true, true>(bl, P, Pu, eps, const_cast<float*>(z) + (int64_t)c * Pu, p + (int64_t)c * Pu,
-                                nullptr, theta + (int64_t)c * P, ll, gl + (int64_t)c * P, lp, g + (int64_t)c * Pu, c);
+                                nullptr, theta + (int64_t)c * P, ll, gl + (int64_t)c * P, lp, g + (int64_t)c * Pu, c, red);
 }
 
-// HMC begin: save the current state, draw (or copy) momenta, record the initial kinetic energy
-__global__ void hmc_begin_kernel(int C, int Pu, uint64_t seed, uint64_t step, const float* __restrict__ z,
-                                 const float* __restrict__ g, const float* __restrict__ lp,
-                                 const float* __restrict__ momenta_in, float* __restrict__ p,
-                                 float* __restrict__ z0, float* __restrict__ g0, float* __restrict__ lp0,
-                                 float* __restrict__ k0) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// HMC begin: save the current state, draw (or copy) momenta, record the initial kinetic energy.
+// One workgroup per chain; a thread owns whole Philox blocks (4 consecutive elements).
+__global__ __launch_bounds__(1024) void hmc_begin_kernel(int C, int Pu, uint64_t seed, uint64_t step,
+                                                         const float* __restrict__ z, const float* __restrict__ g,
+                                                         const float* __restrict__ lp,
+                                                         const float* __restrict__ momenta_in, float* __restrict__ p,
+                                                         float* __restrict__ z0, float* __restrict__ g0,
+                                                         float* __restrict__ lp0, float* __restrict__ k0) {
+  const int c = blockIdx.x;
+  __shared__ float red[16];
   float ke = 0.f;
-  for (int b = 0; 4 * b < Pu; ++b) {
+  for (int b = threadIdx.x; 4 * b < Pu; b += blockDim.x) {
     float v[4];
     if (!momenta_in) normal4(draw(seed, step, c, b, 0), v);
     for (int e = 0; e < 4 && 4 * b + e < Pu; ++e) {
@@ -276,37 +273,46 @@ __global__ void hmc_begin_kernel(int C, int Pu, uint64_t seed, uint64_t step, co
       g0[i] = g[i];
     }
   }
-  lp0[c] = lp[c];
-  k0[c] = ke;
+  ke = block_reduce<false>(ke, red);
+  if (threadIdx.x == 0) {
+    lp0[c] = lp[c];
+    k0[c] = ke;
+  }
 }
 
 // HMC end: Metropolis accept on the energy difference; rejected or non-finite proposals restore the state
-__global__ void hmc_end_kernel(int C, int Pu, uint64_t seed, uint64_t step, const float* __restrict__ log_u_in,
-                               float* __restrict__ z, float* __restrict__ g, float* __restrict__ lp,
-                               const float* __restrict__ p, const float* __restrict__ z0,
-                               const float* __restrict__ g0, const float* __restrict__ lp0,
-                               const float* __restrict__ k0, unsigned char* __restrict__ accepted,
-                               float* __restrict__ log_ratio_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void hmc_end_kernel(int C, int Pu, uint64_t seed, uint64_t step,
+                                                       const float* __restrict__ log_u_in, float* __restrict__ z,
+                                                       float* __restrict__ g, float* __restrict__ lp,
+                                                       const float* __restrict__ p, const float* __restrict__ z0,
+                                                       const float* __restrict__ g0, const float* __restrict__ lp0,
+                                                       const float* __restrict__ k0,
+                                                       unsigned char* __restrict__ accepted,
+                                                       float* __restrict__ log_ratio_out) {
+  const int c = blockIdx.x;
+  __shared__ float red[16];
   float k1 = 0.f;
-  for (int j = 0; j < Pu; ++j) {
+  for (int j = threadIdx.x; j < Pu; j += blockDim.x) {
     const float pj = p[(int64_t)c * Pu + j];
     k1 += 0.5f * pj * pj;
   }
+  k1 = block_reduce<false>(k1, red);
   float lr = (lp[c] - k1) - (lp0[c] - k0[c]);
   if (!isfinite(lr)) lr = -INFINITY;
   const float lu = log_u_in ? log_u_in[c] : logf(u01(draw(seed, step, c, 0, 1).x));
   const bool acc = lu < lr;
+  __syncthreads();                       // every thread has read lp[c] before it may be overwritten
   if (!acc) {
-    for (int j = 0; j < Pu; ++j) {
+    for (int j = threadIdx.x; j < Pu; j += blockDim.x) {
       z[(int64_t)c * Pu + j] = z0[(int64_t)c * Pu + j];
       g[(int64_t)c * Pu + j] = g0[(int64_t)c * Pu + j];
     }
-    lp[c] = lp0[c];
+    if (threadIdx.x == 0) lp[c] = lp0[c];
   }
-  accepted[c] = acc ? 1 : 0;
-  log_ratio_out[c] = lr;
+  if (threadIdx.x == 0) {
+    accepted[c] = acc ? 1 : 0;
+    log_ratio_out[c] = lr;
+  }
 }
 
 inline dim3 chain_grid(int C) { return dim3(bvi_ceil_div(C, 64)); }
@@ -340,7 +346,7 @@ int bvi_constrain(const bvi_param_block* blocks, int n_blocks, int n_chains, con
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !theta || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(constrain_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
+  hipLaunchKernelGGL(constrain_kernel, dim3(n_chains), dim3(chain_threads(P)), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
                      z, theta);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -353,7 +359,7 @@ int bvi_posterior_assemble(const bvi_param_block* blocks, int n_blocks, int n_ch
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !theta || !loglik || !lp || n_chains < 1 || (grad_z && !grad_theta)) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(assemble_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
+  hipLaunchKernelGGL(assemble_kernel, dim3(n_chains), dim3(chain_threads(P)), 0, (hipStream_t)stream, bl, n_chains, P, Pu,
                      z, theta, loglik, grad_theta, lp, grad_z);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -366,7 +372,7 @@ static int launch_pre(const bvi_param_block* blocks, int n_blocks, int n_chains,
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !p || !grad_z || !theta || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(leapfrog_pre_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
+  hipLaunchKernelGGL(leapfrog_pre_kernel, dim3(n_chains), dim3(chain_threads(P)), 0, (hipStream_t)stream, bl, n_chains, P,
                      Pu, step_size, step_sizes, z, p, grad_z, theta);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -380,7 +386,7 @@ static int launch_post(const bvi_param_block* blocks, int n_blocks, int n_chains
   const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
   if (st != BVI_OK) return st;
   if (!z || !p || !theta || !loglik || !grad_theta || !lp || !grad_z || n_chains < 1) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(leapfrog_post_kernel, dim3(n_chains), dim3(64), 0, (hipStream_t)stream, bl, n_chains, P,
+  hipLaunchKernelGGL(leapfrog_post_kernel, dim3(n_chains), dim3(chain_threads(P)), 0, (hipStream_t)stream, bl, n_chains, P,
                      Pu, step_size, step_sizes, z, p, theta, loglik, grad_theta, lp, grad_z);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -417,7 +423,7 @@ int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t ste
                   float* lp0, float* k0, void* stream) {
   if (!z || !grad_z || !lp || !p || !z0 || !g0 || !lp0 || !k0 || n_chains < 1 || n_unconstrained < 1)
     return BVI_ERR_ARG;
-  hipLaunchKernelGGL(hmc_begin_kernel, chain_grid(n_chains), dim3(64), 0, (hipStream_t)stream, n_chains,
+  hipLaunchKernelGGL(hmc_begin_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream, n_chains,
                      n_unconstrained, seed, step, z, grad_z, lp, momenta_in, p, z0, g0, lp0, k0);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -429,7 +435,7 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
   if (!z || !grad_z || !lp || !p || !z0 || !g0 || !lp0 || !k0 || !is_accepted || !log_accept_ratio ||
       n_chains < 1 || n_unconstrained < 1)
     return BVI_ERR_ARG;
-  hipLaunchKernelGGL(hmc_end_kernel, chain_grid(n_chains), dim3(64), 0, (hipStream_t)stream, n_chains,
+  hipLaunchKernelGGL(hmc_end_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream, n_chains,
                      n_unconstrained, seed, step, log_u_in, z, grad_z, lp, p, z0, g0, lp0, k0, is_accepted,
                      log_accept_ratio);
   BVI_HIP_CHECK_LAUNCH();

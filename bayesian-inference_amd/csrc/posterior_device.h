@@ -29,6 +29,28 @@ __device__ __forceinline__ int fill_triangular_src(int d, int f) {
   return f < m - d ? d + f : 2 * m - d - 1 - f;
 }
 
+// Sum / max over the threads of a workgroup of 64 * nw threads (nw <= 16); every thread calls it and gets
+// the result.  `red` is a __shared__ float[16] of the calling kernel.
+template <bool MAX>
+__device__ __forceinline__ float block_reduce(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(v, off, 64);
+    v = MAX ? fmaxf(v, o) : v + o;
+  }
+  const int nw = blockDim.x >> 6;
+  if (nw <= 1) return v;
+  __syncthreads();                 // the previous reduction's readers are done with `red`
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < nw; ++w) r = MAX ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+// threads per chain for the kernels that give one workgroup to each chain's parameter vector
+inline int chain_threads(int n_elements) { return n_elements <= 128 ? 64 : (n_elements <= 2048 ? 256 : 1024); }
+
 // theta = f(z) for one chain; returns fldj(z)
 __device__ float constrain(const Blocks& bl, const float* __restrict__ z, float* __restrict__ theta) {
   float fldj = 0.f;
