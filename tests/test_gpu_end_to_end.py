@@ -605,3 +605,68 @@ def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
     assert [tuple(s.shape) for s in res.samples] == [(30, c, k), (30, c, k, d), (30, c, k, d, d)]
     assert all(bool(torch.isfinite(s).all()) for s in res.samples)
     assert float(res.accept_ratios.mean()) > 0.3
+
+
+@pytest.mark.parametrize('k,d', [(2, 12), (4, 24)])
+def test_fullcov_device_assembly_and_hmc_step_wide_parameter_vectors(bvi, gpu_device, k, d):
+    """Parameter vectors of a few hundred / a few thousand elements (256 / 1024 threads per chain in the
+    state kernels): posterior assembly with the FillScaleTriL block, and one HMC transition through
+    bvi_hmc_begin / bvi_leapfrog_pre / _post / bvi_hmc_end with injected momenta, against the oracle."""
+    import bayes_vi_amd.bijectors as tfb
+    from bayes_vi_amd.inference.mcmc.device_hmc import DeviceHamiltonianMonteCarloKernel
+    from oracle import leapfrog as lf
+    rng = np.random.default_rng(60 + d)
+    n, c = 300, 3
+    m = d * (d + 1) // 2
+    true_mu = rng.integers(-8, 9, (k, d)).astype(np.float64)
+    comp = rng.integers(0, k, n)
+    Y = (true_mu[comp] + rng.normal(size=(n, d))).astype(np.float32)
+    priors = collections.OrderedDict(weights=bvi.tfd.Dirichlet(torch.ones(k) * 2.0),
+                                     locs=bvi.tfd.Normal(torch.zeros(k, d), 10.),
+                                     scale_tril=bvi.tfd.Normal(torch.zeros(k, d, d), 5.))
+    model = bvi.Model(priors, lambda weights, locs, scale_tril: bvi.tfd.MixtureSameFamily(
+        mixture_distribution=bvi.tfd.Categorical(probs=weights),
+        components_distribution=bvi.tfd.MultivariateNormalTriL(loc=locs, scale_tril=scale_tril)),
+        constraining_bijectors=[tfb.SoftmaxCentered(), tfb.Identity(), tfb.FillScaleTriL(d, 1e-3, batch=k)])
+    df = pd.DataFrame(Y, columns=['y%d' % i for i in range(d)])
+    ds = bvi.make_dataset_from_df(df, target_names=list(df.columns))
+    post = bvi.MCMC(model, ds).posterior
+    assert post.device_blocks() is not None
+    pu = (k - 1) + k * d + k * m
+    # start near identity Cholesky factors: packed entries ~ 0 off the diagonal, softplus^-1(1) on it
+    zL = tfb.FillScaleTriL(d, 1e-3, batch=k).inverse(torch.eye(d).repeat(k, 1, 1).reshape(-1)).numpy()
+    z = np.concatenate([rng.normal(0, .2, (c, k - 1)), true_mu.reshape(1, -1) + rng.normal(0, .1, (c, k * d)),
+                        zL[None] + rng.normal(0, .03, (c, k * m))], -1).astype(np.float32)
+    assert z.shape == (c, pu)
+    blocks = [dict(name='w', size=k, prior=('dirichlet', np.ones(k) * 2.0), bijector=cf.SoftmaxCentered()),
+              dict(name='mu', size=k * d, prior=('normal', 0.0, 10.0), bijector=cf.Identity())]
+    blocks += [dict(name='L%d' % i, size=d * d, prior=('normal', 0.0, 5.0), bijector=cf.FillScaleTriL(d, 1e-3))
+               for i in range(k)]
+
+    def lik(th):
+        w, mu, L = th[:, :k], th[:, k:k + k * d].reshape(-1, k, d), th[:, k + k * d:].reshape(-1, k, d, d)
+        lpv, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+        return lpv, np.concatenate([gw, gmu.reshape(len(th), -1), gL.reshape(len(th), -1)], -1)
+    spec = cf.ModelSpec(blocks, lik)
+    zt = torch.tensor(z, device=gpu_device)
+    lp, g = post.unconstrained_log_prob_and_grad(zt)
+    rlp, rg = spec.log_post_unconstrained(z)
+    assert_logp_close(lp.cpu().numpy(), rlp)
+    assert_grad_close(g.cpu().numpy(), rg, term_scale=np.full_like(rg, 3.0 * n))
+    # the generic composition from the bijector objects gives the same numbers
+    saved, post._blocks = post._blocks, None
+    lp_t, g_t = post.unconstrained_log_prob_and_grad(zt)
+    post._blocks = saved
+    assert_logp_close(lp_t.cpu().numpy(), rlp)
+    np.testing.assert_allclose(g.cpu().numpy(), g_t.cpu().numpy(), rtol=2e-4, atol=2e-3 * np.abs(rg).max())
+    eps, L = 2e-3, 3
+    kern = DeviceHamiltonianMonteCarloKernel(post, step_size=eps, num_leapfrog_steps=L, seed=7)
+    p = rng.normal(size=(c, pu)).astype(np.float32); lu = np.log(rng.uniform(size=c)).astype(np.float32)
+    z1, st1, tr = kern.one_step(zt, kern.bootstrap(zt), momenta=torch.tensor(p, device=gpu_device),
+                                log_uniform=torch.tensor(lu, device=gpu_device))
+    q_ref, acc_ref, lr_ref, lp_ref = lf.hmc_step(spec.log_post_unconstrained, z, p, lu, eps, L)
+    safe = np.abs(lu - lr_ref) > 2e-2
+    assert safe.any()
+    np.testing.assert_array_equal(tr['is_accepted'].cpu().numpy()[safe], acc_ref[safe])
+    np.testing.assert_allclose(z1.cpu().numpy()[safe], q_ref[safe], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(tr['log_accept_ratio'].cpu().numpy(), lr_ref, atol=2e-2 + 1e-6 * np.abs(rlp).max())
