@@ -84,7 +84,10 @@ class VI(Inference):
         params = [p for p in self.surrogate_posterior.parameters() if p.requires_grad]
         on_gpu = self.device.type == 'cuda'
         if capture_graph is None:
-            capture_graph = on_gpu and hasattr(optimizer, 'bind') and num_steps > 8
+            # a row-sharded likelihood has a collective inside the step: that stays eager unless asked for
+            lik = self.posterior.likelihood
+            sharded = getattr(lik, 'sharded', False) or getattr(getattr(lik, 'inner', None), 'sharded', False)
+            capture_graph = on_gpu and hasattr(optimizer, 'bind') and num_steps > 8 and not sharded
         if capture_graph and not (on_gpu and hasattr(optimizer, 'bind')):
             raise ValueError('capture_graph needs a GPU run and the built-in Adam description')
         if hasattr(optimizer, 'bind'):
