@@ -85,8 +85,8 @@ def lib():
         l.bvi_nuts_subtree_begin.argtypes = [nsp, u64, u64, i32, vp]
         l.bvi_nuts_leaf.argtypes = [nsp, u64, u64, i32, vp, vp]
         l.bvi_nuts_subtree_end.argtypes = [nsp, vp, vp]
-        l.bvi_hmc_begin.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-        l.bvi_hmc_end.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_hmc_begin.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_hmc_end.argtypes = [i32, i32, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_hmc_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, vp, i32, i32, u64, u64, i32,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_nuts_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, vp, i32, f32, i32, u64, u64, i32,

@@ -15,7 +15,7 @@ from ... import _native
 class DeviceHamiltonianMonteCarloKernel:
     trace_names = ('is_accepted', 'target_log_prob', 'step_size')
 
-    def __init__(self, posterior, step_size=0.01, num_leapfrog_steps=5, seed=0):
+    def __init__(self, posterior, step_size=0.01, num_leapfrog_steps=5, seed=0, graph_replay=False):
         self.posterior = posterior
         self.blocks = posterior.device_blocks()
         if self.blocks is None:
@@ -25,6 +25,7 @@ class DeviceHamiltonianMonteCarloKernel:
         self.num_leapfrog_steps = int(num_leapfrog_steps)
         self.seed = int(seed)
         self.transition = 0
+        self.graph_replay = bool(graph_replay)
         self._bufs = None
 
     def _buffers(self, z):
@@ -40,21 +41,15 @@ class DeviceHamiltonianMonteCarloKernel:
         lp, g = self.posterior.unconstrained_log_prob_and_grad(z, True)
         return {'target_log_prob': lp.contiguous(), 'grad': g.contiguous()}
 
-    def one_step(self, z, state, generator=None, momenta=None, log_uniform=None):
+    def _transition(self, z, g, lp, b, seed, step, momenta=None, log_uniform=None, step_offset=None):
+        """One transition in place on (z, g, lp); accept flags and log ratio land in b['acc'], b['lr']."""
         lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
-        z = z.clone()                       # the kernels update position, gradient and log-prob in place
-        lp = state['target_log_prob'].clone()
-        g = state['grad'].clone()
         c, pu = z.shape
-        b = self._buffers(z)
-        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
-        step = self.transition
-        self.transition += 1
         eps = self.step_size
         _native.check(lib.bvi_hmc_begin(c, pu, seed, step, ptr(z), ptr(g), ptr(lp),
                                         ptr(momenta.contiguous()) if momenta is not None else None,
-                                        ptr(b['p']), ptr(b['z0']), ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']), st),
-                      'bvi_hmc_begin')
+                                        ptr(b['p']), ptr(b['z0']), ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']),
+                                        ptr(step_offset), st), 'bvi_hmc_begin')
         lik = self.posterior.likelihood
         for _ in range(self.num_leapfrog_steps):
             _native.check(lib.bvi_leapfrog_pre(self.blocks, self.nb, c, eps, ptr(z), ptr(b['p']), ptr(g),
@@ -65,11 +60,74 @@ class DeviceHamiltonianMonteCarloKernel:
         _native.check(lib.bvi_hmc_end(c, pu, seed, step,
                                       ptr(log_uniform.contiguous()) if log_uniform is not None else None,
                                       ptr(z), ptr(g), ptr(lp), ptr(b['p']), ptr(b['z0']), ptr(b['g0']),
-                                      ptr(b['lp0']), ptr(b['k0']), ptr(b['acc']), ptr(b['lr']), st), 'bvi_hmc_end')
+                                      ptr(b['lp0']), ptr(b['k0']), ptr(b['acc']), ptr(b['lr']), ptr(step_offset), st),
+                      'bvi_hmc_end')
+
+    def one_step(self, z, state, generator=None, momenta=None, log_uniform=None):
+        z = z.clone().contiguous()          # the kernels update position, gradient and log-prob in place
+        lp = state['target_log_prob'].clone()
+        g = state['grad'].clone()
+        b = self._buffers(z)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        step = self.transition
+        self.transition += 1
+        self._transition(z, g, lp, b, seed, step, momenta, log_uniform)
         acc = b['acc'].to(torch.bool)
         trace = {'is_accepted': acc, 'target_log_prob': lp, 'log_accept_ratio': b['lr'].clone(),
-                 'step_size': torch.full((), eps, dtype=z.dtype)}
+                 'step_size': torch.full((), self.step_size, dtype=z.dtype)}
         return z, {'target_log_prob': lp, 'grad': g}, trace
+
+    supports_many_steps = True
+    GRAPH_MIN_TRANSITIONS = 8
+
+    def many_steps(self, z, state, n, generator=None):
+        """n transitions -> (zs[n, C, Pu], z, state, traces with a leading n axis), enqueued back to back
+        with no host synchronisation; every transition copies its results into row t of the outputs on the
+        stream.  With `graph_replay` one transition -- begin, L x (pre, data pass, post), end, the copies --
+        is recorded once as a HIP graph and replayed; the transition number the Philox draws are keyed by
+        lives in a device word that each transition advances, so the chain is the same either way (and the
+        one `one_step` produces).  Replay only pays when the host cannot keep up with the GPU: measured on
+        an otherwise idle host it is slower than plain launches (77 against 44 us per leapfrog step at
+        N = 200k, D = 32, 64 chains), hence off by default.  A row-sharded likelihood (a collective per
+        leapfrog step) is never captured."""
+        lik = self.posterior.likelihood
+        sharded = getattr(lik, 'sharded', False) or getattr(getattr(lik, 'inner', None), 'sharded', False)
+        z = z.clone().contiguous()
+        lp = state['target_log_prob'].clone()
+        g = state['grad'].clone()
+        c, pu = z.shape
+        b = self._buffers(z)
+        dev = z.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        zs, lps, lrs = f(n, c, pu), f(n, c), f(n, c)
+        accs = torch.empty(n, c, dtype=torch.uint8, device=dev)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        base = self.transition
+        self.transition += n
+        idx = torch.zeros(1, dtype=torch.int64, device=dev)     # transitions done; also the row to write next
+
+        def transition_and_record(step_offset):
+            self._transition(z, g, lp, b, seed, base, step_offset=step_offset)
+            zs.index_copy_(0, idx, z.unsqueeze(0))
+            lps.index_copy_(0, idx, lp.unsqueeze(0))
+            lrs.index_copy_(0, idx, b['lr'].unsqueeze(0))
+            accs.index_copy_(0, idx, b['acc'].unsqueeze(0))
+            idx.add_(1)
+
+        if not self.graph_replay or sharded or n < self.GRAPH_MIN_TRANSITIONS:
+            for _ in range(n):
+                transition_and_record(idx)
+        else:
+            transition_and_record(idx)          # eager: sizes every workspace before the capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                transition_and_record(idx)
+            for _ in range(n - 1):
+                graph.replay()
+        traces = {'is_accepted': accs.to(torch.bool), 'target_log_prob': lps, 'log_accept_ratio': lrs,
+                  'step_size': torch.full((n,), self.step_size, dtype=z.dtype)}
+        return zs, z, {'target_log_prob': lp, 'grad': g}, traces
 
 
 FUSED_MAX_ROWS = 1 << 16     # above this the batched kernels + per-step launches win

@@ -465,24 +465,34 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
   }
 }
 
-// finalize: fixed-order reduction over row blocks (double) + undoing the scales; S1 from the packed data sums
-__global__ void linreg_f16_finalize(const float* __restrict__ partials, const float* __restrict__ ublk, int cpb,
-                                    int nb, int64_t n, int d, const unsigned char* __restrict__ packed,
-                                    const float* __restrict__ theta, int C, float* __restrict__ logp,
-                                    float* __restrict__ grad) {
-  const int q2 = d + 2;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= C * q2) return;
+// finalize: fixed-order reduction over row blocks (double) + undoing the scales; S1 from the packed data sums.
+// A workgroup owns 64 consecutive outputs (coalesced reads of every row block's partials); its 16 waves
+// take every 16th row block and are combined in wave order through LDS.
+constexpr int kFinGroups = 16;
+__global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
+    const float* __restrict__ partials, const float* __restrict__ ublk, int cpb, int nb, int64_t n, int d,
+    const unsigned char* __restrict__ packed, const float* __restrict__ theta, int C, float* __restrict__ logp,
+    float* __restrict__ grad) {
+  const int q2 = d + 2, tot = C * q2;
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
   const int c = idx / q2, q = idx - c * q2;
+  __shared__ double part[kFinGroups][64];
+  double s = 0.0;
+  if (idx < tot && q != 1) {
+#pragma unroll 4
+    for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + idx];
+  }
+  part[grp][o] = s;
+  __syncthreads();
+  if (grp != 0 || idx >= tot) return;
+  for (int w = 1; w < kFinGroups; ++w) s += part[w][o];
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const float* th = theta + (int64_t)c * q2;
   const double u = (double)ublk[c / cpb];
-  double s = 0.0;
   if (q == 1) {
     s = hdr->ysum - (double)n * (double)th[0];
     for (int j = 0; j < d; ++j) s -= (double)th[1 + j] * hdr->colsum[j];
-  } else {
-    for (int b = 0; b < nb; ++b) s += (double)partials[((int64_t)b * C + c) * q2 + q];
   }
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
@@ -570,7 +580,7 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
                      ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * (d + 2);
-  hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, (const float*)ws,
+  hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 64)), dim3(64 * kFinGroups), 0, s, (const float*)ws,
                      (const float*)ublk, cpb, nrb, n, d, pk, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;

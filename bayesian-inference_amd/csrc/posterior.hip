@@ -257,9 +257,11 @@ __global__ __launch_bounds__(1024) void hmc_begin_kernel(int C, int Pu, uint64_t
                                                          const float* __restrict__ lp,
                                                          const float* __restrict__ momenta_in, float* __restrict__ p,
                                                          float* __restrict__ z0, float* __restrict__ g0,
-                                                         float* __restrict__ lp0, float* __restrict__ k0) {
+                                                         float* __restrict__ lp0, float* __restrict__ k0,
+                                                         const uint64_t* __restrict__ step_offset) {
   const int c = blockIdx.x;
   __shared__ float red[16];
+  if (step_offset) step += *step_offset;
   float ke = 0.f;
   for (int b = threadIdx.x; 4 * b < Pu; b += blockDim.x) {
     float v[4];
@@ -288,9 +290,11 @@ __global__ __launch_bounds__(1024) void hmc_end_kernel(int C, int Pu, uint64_t s
                                                        const float* __restrict__ g0, const float* __restrict__ lp0,
                                                        const float* __restrict__ k0,
                                                        unsigned char* __restrict__ accepted,
-                                                       float* __restrict__ log_ratio_out) {
+                                                       float* __restrict__ log_ratio_out,
+                                                       const uint64_t* __restrict__ step_offset) {
   const int c = blockIdx.x;
   __shared__ float red[16];
+  if (step_offset) step += *step_offset;
   float k1 = 0.f;
   for (int j = threadIdx.x; j < Pu; j += blockDim.x) {
     const float pj = p[(int64_t)c * Pu + j];
@@ -420,24 +424,25 @@ int bvi_leapfrog_post_chainwise(const bvi_param_block* blocks, int n_blocks, int
 
 int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* z,
                   const float* grad_z, const float* lp, const float* momenta_in, float* p, float* z0, float* g0,
-                  float* lp0, float* k0, void* stream) {
+                  float* lp0, float* k0, const uint64_t* step_offset, void* stream) {
   if (!z || !grad_z || !lp || !p || !z0 || !g0 || !lp0 || !k0 || n_chains < 1 || n_unconstrained < 1)
     return BVI_ERR_ARG;
   hipLaunchKernelGGL(hmc_begin_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream, n_chains,
-                     n_unconstrained, seed, step, z, grad_z, lp, momenta_in, p, z0, g0, lp0, k0);
+                     n_unconstrained, seed, step, z, grad_z, lp, momenta_in, p, z0, g0, lp0, k0, step_offset);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
 
 int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* log_u_in, float* z,
                 float* grad_z, float* lp, const float* p, const float* z0, const float* g0, const float* lp0,
-                const float* k0, unsigned char* is_accepted, float* log_accept_ratio, void* stream) {
+                const float* k0, unsigned char* is_accepted, float* log_accept_ratio, const uint64_t* step_offset,
+                void* stream) {
   if (!z || !grad_z || !lp || !p || !z0 || !g0 || !lp0 || !k0 || !is_accepted || !log_accept_ratio ||
       n_chains < 1 || n_unconstrained < 1)
     return BVI_ERR_ARG;
   hipLaunchKernelGGL(hmc_end_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream, n_chains,
                      n_unconstrained, seed, step, log_u_in, z, grad_z, lp, p, z0, g0, lp0, k0, is_accepted,
-                     log_accept_ratio);
+                     log_accept_ratio, step_offset);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

@@ -186,7 +186,9 @@ int bvi_posterior_assemble(const bvi_param_block* blocks, int n_blocks, int n_ch
  * bvi_hmc_begin saves (z, grad_z, lp), draws the momenta p ~ N(0, I) with Philox4x32-10 keyed by
  * (seed; step, chain, element) unless momenta_in is given, and records the kinetic energy;
  * bvi_hmc_end accepts with probability min(1, exp(-dH)) (uniform from the same generator unless
- * log_u_in is given) and restores the saved state of rejected chains; non-finite energies reject. */
+ * log_u_in is given) and restores the saved state of rejected chains; non-finite energies reject.
+ * step_offset (device pointer, may be NULL) is added to `step` when the kernel runs: a transition recorded
+ * once as a HIP graph draws fresh numbers at every replay if the caller advances that word in between. */
 int bvi_leapfrog_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, float* z,
                      float* p, const float* grad_z, float* theta, void* stream);
 int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
@@ -194,11 +196,11 @@ int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains,
                       float* grad_z, void* stream);
 int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* z,
                   const float* grad_z, const float* lp, const float* momenta_in, float* p, float* z0, float* g0,
-                  float* lp0, float* k0, void* stream);
+                  float* lp0, float* k0, const uint64_t* step_offset, void* stream);
 int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* log_u_in,
                 float* z, float* grad_z, float* lp, const float* p, const float* z0, const float* g0,
                 const float* lp0, const float* k0, unsigned char* is_accepted, float* log_accept_ratio,
-                void* stream);
+                const uint64_t* step_offset, void* stream);
 
 /* The two leapfrog halves with one signed step size per chain (step_sizes[C]; 0 leaves a chain untouched):
  * what the No-U-Turn sampler needs, whose chains integrate forwards or backwards in time and stop at

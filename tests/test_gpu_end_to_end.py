@@ -271,6 +271,36 @@ def test_device_hmc_matches_oracle_with_injected_and_philox_randomness(bvi, gpu_
     np.testing.assert_allclose(z2.cpu().numpy()[safe], q_ref2[safe], rtol=5e-5, atol=5e-5)
 
 
+def test_device_hmc_graph_replay_gives_the_chain_of_single_steps(bvi, gpu_device):
+    """DeviceHamiltonianMonteCarloKernel.many_steps (one transition recorded as a HIP graph, Philox
+    transition number advanced on the device) against the same kernel stepped launch by launch: same
+    positions, accept decisions and log densities, transition for transition."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import DeviceHamiltonianMonteCarloKernel
+    rng = np.random.default_rng(77)
+    for name, model, ds, spec, z in _fused_cases(bvi, rng):
+        post = bvi.MCMC(model, ds).posterior
+        eps = {'normal': 0.2, 'linreg': 0.01, 'gmm1d': 0.04}[name]
+        zt = torch.tensor(z.astype(np.float32), device=gpu_device)
+        T = 12
+        a = DeviceHamiltonianMonteCarloKernel(post, step_size=eps, num_leapfrog_steps=3, seed=21, graph_replay=True)
+        zs, zf, stf, tr = a.many_steps(zt, a.bootstrap(zt), T)
+        assert a.transition == T
+        b = DeviceHamiltonianMonteCarloKernel(post, step_size=eps, num_leapfrog_steps=3, seed=21)
+        zc, st = zt, b.bootstrap(zt)
+        for t in range(T):
+            zc, st, tr1 = b.one_step(zc, st)
+            assert torch.equal(tr['is_accepted'][t], tr1['is_accepted']), (name, t)
+            assert torch.equal(zs[t], zc), (name, t)
+            assert torch.equal(tr['target_log_prob'][t], st['target_log_prob']), (name, t)
+            assert torch.equal(tr['log_accept_ratio'][t], tr1['log_accept_ratio']), (name, t)
+        assert torch.equal(zf, zc) and torch.equal(stf['grad'], st['grad'])
+        assert 0 < float(tr['is_accepted'].float().mean()) <= 1
+        # a second call continues the same chain
+        zs2, _, _, _ = a.many_steps(zf, stf, 9)
+        zc2, st2, _ = b.one_step(zc, st)
+        assert torch.equal(zs2[0], zc2), name
+
+
 def _fused_cases(bvi, rng):
     """(name, model, dataset, oracle spec, start point z[C, Pu]) for the three families of the fused HMC kernel."""
     out = []
