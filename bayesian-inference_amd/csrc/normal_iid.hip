@@ -10,7 +10,8 @@
 // Lane mapping: a wave holds CP chains x (64/CP) row subsets, lane = chain +
 // CP*rowsub.  Each wave loads 64 consecutive y (one coalesced 256-B read) and
 // hands them round with lane shuffles, so every lane sees the rows of its
-// subset without re-reading memory.  Sums are two-level in registers (per
+// subset without re-reading memory; with 64 chains per wave (every lane needs
+// every row) the rows are scalar loads instead.  Sums are two-level in registers (per
 // 64-row tile, then running total), butterfly-reduced over row subsets, tree-
 // reduced over the 4 waves through LDS, and written as one partial per
 // workgroup; finalize adds the partials in fixed order in double.
@@ -21,16 +22,33 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
                                                          const float* __restrict__ theta, int C,
                                                          float* __restrict__ partials) {
   constexpr int RS = 64 / CP;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction
   const int cl = lane & (CP - 1), rsub = lane / CP;
   const int chain = blockIdx.y * CP + cl;
   const float mu = chain < C ? theta[2 * chain] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    float a1 = 0.f, a2 = 0.f;
+    if (CP == 64 && t * 64 + 64 <= n) {
+      // lane = chain: every lane needs the same 64 rows, so they come through the scalar data path
+      // (wave-uniform address, read-only data) and reach the vector ALU as scalar operands -- no LDS
+      // round trip per row, three vector instructions per (row, chain)
+      const float* __restrict__ yt = y + t * 64;
+      float b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;   // four independent chains
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float r0 = yt[j] - mu, r1 = yt[16 + j] - mu, r2 = yt[32 + j] - mu, r3 = yt[48 + j] - mu;
+        a1 += r0; b1 += r1; c1 += r2; d1 += r3;
+        a2 = fmaf(r0, r0, a2); b2 = fmaf(r1, r1, b2); c2 = fmaf(r2, r2, c2); d2 = fmaf(r3, r3, d2);
+      }
+      s1 += (a1 + b1) + (c1 + d1);
+      s2 += (a2 + b2) + (c2 + d2);
+      continue;
+    }
     const int64_t i = t * 64 + lane;
     const float yv = i < n ? y[i] : 0.f;
-    float a1 = 0.f, a2 = 0.f;
     if (t * 64 + 64 <= n) {
 #pragma unroll
       for (int j = 0; j < CP; ++j) {
@@ -75,6 +93,73 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
   }
 }
 
+// Few chains per group (CG = 1, 4, 16): every lane streams rows of its own -- 16-byte loads, four in flight --
+// and carries the sums of all CG chains in registers; no lane exchange until the final reduction.
+// (With one 4-byte load per lane and iteration, as in the shuffle mapping above, a wave has 256 B in flight
+// and the loop runs at memory latency, not bandwidth.)
+template <int CG>
+__global__ __launch_bounds__(256) void normal_iid_rows_kernel(const float* __restrict__ y, int64_t n,
+                                                              const float* __restrict__ theta, int C,
+                                                              float* __restrict__ partials) {
+  constexpr int U = 4;
+  const int c0 = blockIdx.y * CG;
+  float mu[CG], s1[CG], s2[CG];
+#pragma unroll
+  for (int k = 0; k < CG; ++k) {
+    mu[k] = c0 + k < C ? theta[2 * (c0 + k)] : 0.f;
+    s1[k] = 0.f;
+    s2[k] = 0.f;
+  }
+  auto row = [&](float yv) {
+#pragma unroll
+    for (int k = 0; k < CG; ++k) {
+      const float r = yv - mu[k];
+      s1[k] += r;
+      s2[k] = fmaf(r, r, s2[k]);
+    }
+  };
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  // rows before the first 16-byte boundary, then whole float4s, then the last few rows
+  int64_t head = (int64_t)(((16 - ((uintptr_t)y & 15)) & 15) >> 2);
+  if (head > n) head = n;
+  const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>(y + head);
+  const int64_t n4 = (n - head) >> 2, tail0 = head + 4 * n4;
+  int64_t i = tid;
+  for (; i + (U - 1) * nth < n4; i += U * nth) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = y4[i + u * nth];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row(v[u].x); row(v[u].y); row(v[u].z); row(v[u].w);
+    }
+  }
+  for (; i < n4; i += nth) {
+    const f32x4 v = y4[i];
+    row(v.x); row(v.y); row(v.z); row(v.w);
+  }
+  if (tid < head) row(y[tid]);
+  if (tid < n - tail0) row(y[tail0 + tid]);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float sm[4][CG][2];
+#pragma unroll
+  for (int k = 0; k < CG; ++k) {
+    const float t1 = bvi_reduce_over_rowsubs<1>(s1[k]), t2 = bvi_reduce_over_rowsubs<1>(s2[k]);
+    if (lane == 0) {
+      sm[wave][k][0] = t1;
+      sm[wave][k][1] = t2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < CG && c0 + threadIdx.x < C) {
+    const int k = threadIdx.x;
+    float* p = partials + ((int64_t)blockIdx.x * C + c0 + k) * 2;
+    p[0] = (sm[0][k][0] + sm[1][k][0]) + (sm[2][k][0] + sm[3][k][0]);
+    p[1] = (sm[0][k][1] + sm[1][k][1]) + (sm[2][k][1] + sm[3][k][1]);
+  }
+}
+
 // one thread (WAVE = false) or one wave (WAVE = true) per chain
 template <bool WAVE>
 __global__ void normal_iid_finalize(const float* __restrict__ partials, int nb, int64_t n,
@@ -107,9 +192,9 @@ int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, 
   const int cp = bvi_chain_pack(c);
   dim3 grid(nb, bvi_ceil_div(c, cp));
   switch (cp) {
-    case 1: hipLaunchKernelGGL(normal_iid_kernel<1>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
-    case 4: hipLaunchKernelGGL(normal_iid_kernel<4>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
-    case 16: hipLaunchKernelGGL(normal_iid_kernel<16>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
+    case 1: hipLaunchKernelGGL(normal_iid_rows_kernel<1>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
+    case 4: hipLaunchKernelGGL(normal_iid_rows_kernel<4>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
+    case 16: hipLaunchKernelGGL(normal_iid_rows_kernel<16>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
     default: hipLaunchKernelGGL(normal_iid_kernel<64>, grid, dim3(256), 0, s, y, n, theta, c, ws); break;
   }
   BVI_HIP_CHECK_LAUNCH();

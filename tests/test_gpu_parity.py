@@ -67,6 +67,25 @@ def test_normal_iid_empty(nat, ws, gpu_device):
     np.testing.assert_array_equal(g.cpu().numpy(), np.zeros((2, 2)))
 
 
+@pytest.mark.parametrize('c', [1, 3, 16, 70])
+def test_normal_iid_unaligned_rows_and_short_inputs(nat, ws, gpu_device, c):
+    """Row pointers off the 16-byte grid (a view into a larger tensor) and inputs shorter than one
+    vector load: head rows, whole 16-byte groups and tail rows must each be counted exactly once."""
+    rng = np.random.default_rng(500 + c)
+    base = rng.normal(-3, 2, 5000).astype(np.float32)
+    base_dev = dev(base, gpu_device)
+    th = np.stack([rng.normal(-3, 0.5, c), rng.uniform(1, 3, c)], -1).astype(np.float32)
+    for off in (0, 1, 2, 3):
+        for n in (1, 2, 3, 4, 5, 7, 8, 9, 1003, 4997 - off):
+            y = base[off:off + n]
+            ref_lp, ref_g = cf.normal_iid(y, th)
+            lp, g = nat.normal_iid_logp_grad(base_dev[off:off + n], dev(th, gpu_device), ws)
+            r = np.abs(y[None] - th[:, :1]); sc = th[:, 1:2].astype(np.float64)
+            assert_logp_close(lp.cpu().numpy(), ref_lp)
+            assert_grad_close(g.cpu().numpy(), ref_g,
+                              term_scale=np.stack([(r / sc ** 2).sum(-1), (r * r / sc[:, :1] ** 3).sum(-1) + n / sc[:, 0]], -1))
+
+
 def _linreg_case(rng, n, d, c, spread=0.05):
     X = rng.normal(size=(n, d)).astype(np.float32)
     w = rng.normal(size=d)
