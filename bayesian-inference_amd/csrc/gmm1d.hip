@@ -114,6 +114,114 @@ __global__ __launch_bounds__(256) void gmm1d_kernel(const float* __restrict__ y,
   }
 }
 
+// Few chains per group (CG = 1 or 4): every lane streams rows of its own with 16-byte loads and carries the
+// sums of all CG chains in registers; the chains' parameters are wave-uniform (scalar registers).  The shuffle
+// mapping above issues one 4-byte load per lane and iteration, which leaves too little in flight when the
+// per-row work is small (one or a few chains).
+template <int K, int CG>
+__global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict__ y, int64_t n, int kreal,
+                                                         const float* __restrict__ theta, int C,
+                                                         float* __restrict__ partials) {
+  constexpr int Q = 1 + 3 * K;
+  const int c0 = blockIdx.y * CG;
+  float B[CG][K], mu[CG][K], isg[CG][K];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const float* th = theta + (int64_t)(c0 + g < C ? c0 + g : 0) * 3 * kreal;   // padding chains: results dropped
+    float wsum = 0.f;
+    for (int k = 0; k < kreal; ++k) wsum += th[k];
+    const float lw = __log2f(wsum);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (k < kreal) {
+        const float w = th[k], sc = th[2 * kreal + k];
+        mu[g][k] = th[kreal + k];
+        B[g][k] = __log2f(w) - lw - __log2f(sc) - 0.5f * BVI_LN2PI * BVI_LOG2E;
+        isg[g][k] = 0.84932180028801904f / sc;  // sqrt(log2(e)/2)
+      } else {
+        mu[g][k] = 0.f;
+        B[g][k] = -INFINITY;
+        isg[g][k] = 0.f;
+      }
+    }
+  }
+  float acc[CG][Q];
+#pragma unroll
+  for (int g = 0; g < CG; ++g)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[g][q] = 0.f;
+  auto row = [&](float yj) {
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+      float u[K], a[K];
+      float m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        u[k] = (yj - mu[g][k]) * isg[g][k];
+        a[k] = fmaf(-u[k], u[k], B[g][k]);
+        m = fmaxf(m, a[k]);
+      }
+      float ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        a[k] = __builtin_amdgcn_exp2f(a[k] - m);
+        ssum += a[k];
+      }
+      acc[g][0] += m + __builtin_amdgcn_logf(ssum);
+      const float inv = __builtin_amdgcn_rcpf(ssum);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float rho = a[k] * inv;
+        const float ru = rho * u[k];
+        acc[g][1 + k] += rho;
+        acc[g][1 + K + k] += ru;
+        acc[g][1 + 2 * K + k] = fmaf(ru, u[k], acc[g][1 + 2 * K + k]);
+      }
+    }
+  };
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  int64_t head = (int64_t)(((16 - ((uintptr_t)y & 15)) & 15) >> 2);
+  if (head > n) head = n;
+  const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>(y + head);
+  const int64_t n4 = (n - head) >> 2, tail0 = head + 4 * n4;
+  int64_t i = tid;
+  for (; i + nth < n4; i += 2 * nth) {
+    const f32x4 v0 = y4[i], v1 = y4[i + nth];
+    row(v0.x); row(v0.y); row(v0.z); row(v0.w);
+    row(v1.x); row(v1.y); row(v1.z); row(v1.w);
+  }
+  for (; i < n4; i += nth) {
+    const f32x4 v = y4[i];
+    row(v.x); row(v.y); row(v.z); row(v.w);
+  }
+  if (tid < head) row(y[tid]);
+  if (tid < n - tail0) row(y[tail0 + tid]);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float sm[4][CG][Q];
+#pragma unroll
+  for (int g = 0; g < CG; ++g)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float v = bvi_reduce_over_rowsubs<1>(acc[g][q]);
+      if (lane == 0) sm[wave][g][q] = v;
+    }
+  __syncthreads();
+  // raw layout per chain: [L2, A0[kreal], A1[kreal], A2[kreal]]
+  const int qreal = 1 + 3 * kreal;
+  for (int idx = threadIdx.x; idx < CG * qreal; idx += 256) {
+    const int g = idx / qreal, q = idx - g * qreal;
+    if (c0 + g >= C) continue;
+    int qs = 0;
+    if (q > 0) {
+      const int part = (q - 1) / kreal, k = (q - 1) - part * kreal;
+      qs = 1 + part * K + k;
+    }
+    partials[((int64_t)blockIdx.x * C + c0 + g) * qreal + q] =
+        (sm[0][g][qs] + sm[1][g][qs]) + (sm[2][g][qs] + sm[3][g][qs]);
+  }
+}
+
 // one thread (WAVE = false) or one wave (WAVE = true) per gradient entry
 template <bool WAVE>
 __global__ void gmm1d_finalize(const float* __restrict__ partials, int nb, int64_t n, int k,
@@ -162,8 +270,11 @@ template <int K>
 static void gmm1d_dispatch_cp(int cp, dim3 grid, hipStream_t s, const float* y, int64_t n, int k,
                               const float* theta, int c, float* ws) {
   switch (cp) {
-    case 1: hipLaunchKernelGGL((gmm1d_kernel<K, 1>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
-    case 4: hipLaunchKernelGGL((gmm1d_kernel<K, 4>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
+    case 1: hipLaunchKernelGGL((gmm1d_rows_kernel<K, 1>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
+    case 4:
+      if (K <= 8) hipLaunchKernelGGL((gmm1d_rows_kernel<K <= 8 ? K : 8, 4>), grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+      else hipLaunchKernelGGL((gmm1d_kernel<K, 4>), grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+      break;
     case 16: hipLaunchKernelGGL((gmm1d_kernel<K, 16>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
     default: hipLaunchKernelGGL((gmm1d_kernel<K, 64>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
   }

@@ -320,6 +320,26 @@ def test_nonfinite_parameters_propagate(nat, ws, gpu_device):
     assert not np.isfinite(lp[0]) and not np.isfinite(lp[1]) and np.isfinite(lp[2])
 
 
+@pytest.mark.parametrize('k,c', [(3, 1), (8, 4), (16, 3), (5, 9)])
+def test_gmm1d_unaligned_rows_and_short_inputs(nat, ws, gpu_device, k, c):
+    """Views that start off the 16-byte grid and inputs shorter than one vector load (the row-streaming
+    kernel of 1 - 4 chains splits the rows into head / 16-byte groups / tail)."""
+    rng = np.random.default_rng(900 + k + c)
+    locs = np.linspace(-10, 10, k)
+    base = rng.normal(locs[rng.integers(0, k, 3000)], 1.0).astype(np.float32)
+    base_dev = dev(base, gpu_device)
+    th = np.concatenate([rng.dirichlet(np.ones(k) * 5, c), locs + rng.normal(0, .3, (c, k)),
+                         rng.uniform(0.8, 1.3, (c, k))], -1).astype(np.float32)
+    for off in (0, 1, 2, 3):
+        for n in (1, 3, 4, 6, 9, 1001, 2997 - off):
+            y = base[off:off + n]
+            ref_lp, ref_g = cf.gmm1d(y, th, k)
+            lp, g = nat.gmm1d_logp_grad(base_dev[off:off + n], dev(th, gpu_device), k, ws)
+            ts = np.concatenate([n / th[:, :k], n / th[:, 2 * k:] * np.ones((c, k)), 3 * n / th[:, 2 * k:]], -1) * 0.3
+            assert_logp_close(lp.cpu().numpy(), ref_lp)
+            assert_grad_close(g.cpu().numpy(), ref_g, term_scale=ts)
+
+
 @pytest.mark.parametrize('k,c,n', [(1, 1, 10), (2, 4, 100), (3, 5, 999), (5, 2, 64), (8, 4, 4096), (8, 64, 3000),
                                    (8, 70, 20001), (16, 3, 500), (4, 16, 100000)])
 def test_gmm1d(nat, ws, gpu_device, k, c, n):
