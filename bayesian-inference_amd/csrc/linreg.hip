@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void linreg_valu_kernel(const float* __restric
                                                           float* __restrict__ partials) {
   constexpr int RS = 64 / CP;
   constexpr int Q = DP + 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction
   const int cl = lane & (CP - 1), rsub = lane / CP;
   const int chain = blockIdx.y * CP + cl;
   float b0 = 0.f, w[DP];
@@ -46,6 +47,28 @@ __global__ __launch_bounds__(256) void linreg_valu_kernel(const float* __restric
   for (int q = 0; q < Q; ++q) tot[q] = 0.f;
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    if (CP == 64 && d == DP && t * 64 + 64 <= n) {
+      // lane = chain: every lane needs the same 64 rows, so they come through the scalar data path
+      // (wave-uniform addresses, read-only data, compile-time row stride: wide scalar loads) and reach
+      // the vector ALU as scalar operands
+      const float* __restrict__ yt = y + t * 64;
+      const float* __restrict__ Xt = X + t * 64 * DP;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) {
+        float r = yt[j] - b0;
+        float xj[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+          xj[k] = Xt[j * DP + k];
+          r = fmaf(-w[k], xj[k], r);
+        }
+        tot[0] = fmaf(r, r, tot[0]);
+        tot[1] += r;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) tot[2 + k] = fmaf(r, xj[k], tot[2 + k]);
+      }
+      continue;
+    }
     const int64_t i = t * 64 + lane;
     const bool ok = i < n;
     const float yv = ok ? y[i] : 0.f;
@@ -88,6 +111,92 @@ __global__ __launch_bounds__(256) void linreg_valu_kernel(const float* __restric
     const int gc = blockIdx.y * CP + c;
     if (gc >= C) continue;
     partials[((int64_t)blockIdx.x * C + gc) * qreal + q] = sm[0][c][q] + sm[1][c][q] + sm[2][c][q] + sm[3][c][q];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// d in {1, 2, 4, 8}, 16-byte aligned X and y, few chains (CG = 1 or 4 per group): every lane owns groups of four
+// consecutive rows -- d + 1 16-byte loads per group, two groups in flight -- and carries the sums of all CG
+// chains in registers; the chains' parameters are wave-uniform (scalar registers).  No lane exchange before
+// the final reduction.
+// ---------------------------------------------------------------------------
+template <int DP, int CG>
+__global__ __launch_bounds__(256) void linreg_rows_kernel(const float* __restrict__ X, const float* __restrict__ y,
+                                                          int64_t n, const float* __restrict__ theta, int C,
+                                                          float* __restrict__ partials) {
+  constexpr int Q = DP + 2;
+  const int c0 = blockIdx.y * CG;
+  float b0[CG], w[CG][DP], acc[CG][Q];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const float* th = theta + (int64_t)(c0 + g < C ? c0 + g : 0) * (DP + 2);   // padding chains: results dropped
+    b0[g] = th[0];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) w[g][k] = th[1 + k];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[g][q] = 0.f;
+  }
+  auto row = [&](float yv, const float* x) {
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+      float r = yv - b0[g];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) r = fmaf(-w[g][k], x[k], r);
+      acc[g][0] = fmaf(r, r, acc[g][0]);
+      acc[g][1] += r;
+#pragma unroll
+      for (int k = 0; k < DP; ++k) acc[g][2 + k] = fmaf(r, x[k], acc[g][2 + k]);
+    }
+  };
+  auto group = [&](const f32x4& yv, const f32x4 (&xv)[DP]) {
+    float flat[4 * DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) flat[4 * k + e] = xv[k][e];
+    row(yv.x, flat); row(yv.y, flat + DP); row(yv.z, flat + 2 * DP); row(yv.w, flat + 3 * DP);
+  };
+  const f32x4* __restrict__ X4 = reinterpret_cast<const f32x4*>(X);
+  const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>(y);
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  const int64_t n4 = n >> 2;
+  int64_t i = tid;
+  for (; i + nth < n4; i += 2 * nth) {
+    f32x4 ya = y4[i], yb = y4[i + nth], xa[DP], xb[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xa[k] = X4[i * DP + k];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xb[k] = X4[(i + nth) * DP + k];
+    group(ya, xa);
+    group(yb, xb);
+  }
+  for (; i < n4; i += nth) {
+    f32x4 ya = y4[i], xa[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xa[k] = X4[i * DP + k];
+    group(ya, xa);
+  }
+  if (tid < n - 4 * n4) {
+    const int64_t r = 4 * n4 + tid;
+    float x[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) x[k] = X[r * DP + k];
+    row(y[r], x);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float sm[4][CG][Q];
+#pragma unroll
+  for (int g = 0; g < CG; ++g)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float v = bvi_reduce_over_rowsubs<1>(acc[g][q]);
+      if (lane == 0) sm[wave][g][q] = v;
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < CG * Q; idx += 256) {
+    const int g = idx / Q, q = idx - g * Q;
+    if (c0 + g >= C) continue;
+    partials[((int64_t)blockIdx.x * C + c0 + g) * Q + q] = (sm[0][g][q] + sm[1][g][q]) + (sm[2][g][q] + sm[3][g][q]);
   }
 }
 
@@ -347,6 +456,15 @@ size_t bvi_ws_linreg(int64_t n, int c, int d) {
 template <int DP>
 static void linreg_valu_dispatch(int cp, dim3 grid, hipStream_t s, const float* X, const float* y, int64_t n,
                                  int d, const float* theta, int c, float* ws) {
+  const bool rows_ok = d == DP && (((uintptr_t)X | (uintptr_t)y) & 15) == 0;
+  if (rows_ok && cp == 1) {
+    hipLaunchKernelGGL((linreg_rows_kernel<DP, 1>), grid, dim3(256), 0, s, X, y, n, theta, c, ws);
+    return;
+  }
+  if (rows_ok && cp == 4) {
+    hipLaunchKernelGGL((linreg_rows_kernel<DP, 4>), grid, dim3(256), 0, s, X, y, n, theta, c, ws);
+    return;
+  }
   switch (cp) {
     case 1: hipLaunchKernelGGL((linreg_valu_kernel<DP, 1>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ws); break;
     case 4: hipLaunchKernelGGL((linreg_valu_kernel<DP, 4>), grid, dim3(256), 0, s, X, y, n, d, theta, c, ws); break;

@@ -106,7 +106,8 @@ def _linreg_term_scale(X, y, th):
 
 
 @pytest.mark.parametrize('d,c,n', [(1, 2, 50), (1, 1, 1), (2, 5, 100), (3, 16, 777), (5, 33, 4096), (8, 64, 1000),
-                                   (8, 100, 20011), (12, 4, 500), (16, 16, 1024), (31, 7, 333), (32, 33, 2048),
+                                   (8, 100, 20011), (4, 1, 1003), (4, 4, 5001), (8, 3, 2049), (2, 1, 777),
+                                   (1, 64, 5000), (2, 70, 3001), (4, 64, 4100), (1, 4, 100003), (12, 4, 500), (16, 16, 1024), (31, 7, 333), (32, 33, 2048),
                                    (33, 5, 100), (48, 64, 4099), (64, 2, 20), (64, 100, 8192), (64, 17, 100003)])
 def test_linreg_f32(nat, ws, gpu_device, d, c, n):
     rng = np.random.default_rng(7 * d + c + n)
@@ -290,6 +291,22 @@ def test_linreg_errors(nat, ws, gpu_device):
         nat.linreg_logp_grad(X, y, th, ws, precision=nat.PREC_BF16X6)
     with pytest.raises(nat.BviError):
         nat.linreg_logp_grad(X.cpu(), y, th, ws)
+
+
+@pytest.mark.parametrize('d', [1, 2, 4, 8])
+def test_linreg_small_d_unaligned_rows(nat, ws, gpu_device, d):
+    """Few features, few chains: the row-streaming kernel needs 16-byte aligned X and y; a view that starts
+    off that grid (a shard cut at an odd row) takes the guarded kernel and gives the same sums."""
+    rng = np.random.default_rng(40 + d)
+    n = 3001
+    X, y, th = _linreg_case(rng, n + 3, d, 3)
+    Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
+    for off in (0, 1, 2, 3):
+        Xs, ys = X[off:off + n], y[off:off + n]
+        ref_lp, ref_g = cf.linreg(Xs, ys, th)
+        lp, g = nat.linreg_logp_grad(Xd[off:off + n], yd[off:off + n], thd, ws, precision=nat.PREC_F32)
+        assert_logp_close(lp.cpu().numpy(), ref_lp)
+        assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(Xs, ys, th))
 
 
 def test_streaming_kernels_accept_unaligned_data(nat, ws, gpu_device):
