@@ -1,11 +1,17 @@
 // Linear-regression raw sums for many chains on the f16 matrix cores, operands split into f16
 // pieces of range-normalised values (11 significant bits each, plus one from round-to-nearest).
-// Residual GEMM, 4 products: X = xh + xl (error <= 1 f32 ulp, independent from row to row, so it
-// averages out over rows) times W = w1 + w2 + w3 (exact): xh.w1, xl.w1, xh.w2, xh.w3.  The third
-// piece of W matters although it is 2^-22 of W: an error in W is the same for every row, so it
-// acts like evaluating the gradient at a shifted parameter and grows with n, not sqrt(n).
+// Residual GEMM, 3 products: X = xh + xl (error <= 1 f32 ulp, independent from row to row, so it
+// averages out over rows) times W = w1 + w2: xh.w1, xl.w1, xh.w2.  What two f16 pieces leave of W,
+// dw = w - (w1 + w2) ~ 2^-22 w, matters all the same: an error in W is the same for every row, so
+// it acts like evaluating the gradient at a shifted parameter and grows with n, not sqrt(n).  But
+// exactly because it is one vector per chain its effect is known in closed form: the kernel's
+// residuals are r + X dw, hence
+//   G = G_kernel - (X^T X) dw,     S2 = S2_kernel - 2 dw . G_kernel + dw . (X^T X) dw,
+// and the finalize kernel applies these corrections in double, with X^T X (D x D) taken once, in
+// double, at pack time.  (They are 2^-22-sized; a third piece product xh.w3 did the same job at the
+// price of one more MFMA per tile and chain block: 6.5 ms against 5.8 ms at the headline shape.)
 // Gradient GEMM, 3 products: R = rh + rl times X: rh.xh, rl.xh, rh.xl.
-// 7 f16 products where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3 products) needs 9, on two
+// 6 f16 products where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3 products) needs 9, on two
 // 2-byte planes of X (= the size of the f32 matrix) instead of three.
 // Same likelihood node as there: tfd.Normal(beta_0 + X w, scale)
 // (bayes_vi/model/model.py:194-203, README.md:754-756).
@@ -29,6 +35,7 @@
 //
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
 //   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
+//   gram   [64][64] double: X^T X (rows / columns beyond the model's features are zero)
 //   planes [2][n_pad][D] f16: hi(x'), lo(x')           (D = 32 or 64 >= the model's feature count; padding
 //                                                       rows and columns are zero)
 //   y      [n_pad] f32                                 (0 for padding rows)
@@ -50,7 +57,8 @@
 namespace {
 
 constexpr int kTileRows = 128;             // rows staged per barrier; processed as 64-row halves
-constexpr int kHeader = 1024;
+constexpr int kGramOffset = 1024;                       // X^T X, [64][64] double, behind the Header struct
+constexpr int kHeader = kGramOffset + 64 * 64 * 8;      // everything in front of the planes
 constexpr int kMaxRowBlocks = 256;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -64,7 +72,7 @@ struct Header {
   double ysum;
   float ymax;
 };
-static_assert(sizeof(Header) <= kHeader, "header must fit");
+static_assert(sizeof(Header) <= kGramOffset, "header must fit");
 
 // scale of the residuals for the gradient GEMM: |r| <= ymax + |b0| + D * 2^14 * max|w / colscale|
 __device__ __forceinline__ float resid_scale(float amax_v, float b0, float ymax, int d) {
@@ -127,8 +135,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const unsigned char* planes = packed + kHeader;
   const unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
 
-  // scaled -W fragments in three f16 pieces; per chain: c1 = u / t and nb0 = -b0
-  f16x8 w1[2][KS], w2[2][KS], w3[2][KS];
+  // scaled -W fragments in two f16 pieces; per chain: c1 = u / t and nb0 = -b0
+  f16x8 w1[2][KS], w2[2][KS];
   float nb0[2], c1[2];
   float u;
   {
@@ -161,8 +169,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           const _Float16 hi = (_Float16)q;
           const _Float16 lo = (_Float16)(q - (float)hi);
           w1[ct][ks][j] = hi;
-          w2[ct][ks][j] = lo;
-          w3[ct][ks][j] = (_Float16)((q - (float)hi) - (float)lo);
+          w2[ct][ks][j] = lo;       // what is left, (q - hi) - lo, is accounted for in the finalize kernel
         }
     }
 #pragma unroll
@@ -283,7 +290,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w2[ct][ks], z[ct], 0, 0, 0);
-          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w3[ct][ks], z[ct], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -465,47 +471,128 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
   }
 }
 
-// finalize: fixed-order reduction over row blocks (double) + undoing the scales; S1 from the packed data sums.
-// A workgroup owns 64 consecutive outputs (coalesced reads of every row block's partials); its 16 waves
-// take every 16th row block and are combined in wave order through LDS.
+// X^T X in double, stage 1: block b takes the 64-row tiles b, b + nblk, ...; a thread owns an E x E block of
+// the matrix (E = D / 16).  Partials [nblk][64][64]; only the D x D corner is written.
+constexpr int kGramBlocks = 256;
+template <int D>
+__global__ __launch_bounds__(256) void f16_gram_kernel(const float* __restrict__ X, int64_t n, int dr,
+                                                       double* __restrict__ gpart) {
+  constexpr int E = D / 16;
+  __shared__ float xt[64][D + 1];
+  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+  double acc[E][E];
+#pragma unroll
+  for (int i = 0; i < E; ++i)
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[i][j] = 0.0;
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * D; e += 256) {
+      const int r = e / D, col = e - r * D;
+      const int64_t row = t * 64 + r;
+      xt[r][col] = (row < n && col < dr) ? X[row * dr + col] : 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) {
+      double xa[E], xb[E];
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        xa[i] = (double)xt[r][E * a + i];
+        xb[i] = (double)xt[r][E * b + i];
+      }
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[i][j] = fma(xa[i], xb[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i)
+#pragma unroll
+    for (int j = 0; j < E; ++j) gpart[((int64_t)blockIdx.x * 64 + E * a + i) * 64 + E * b + j] = acc[i][j];
+}
+
+// stage 2: fixed-order sum of the partials; entries outside the D x D corner are zero
+__global__ void f16_gram_final(const double* __restrict__ gpart, int nblk, int D, double* __restrict__ gram) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 64 * 64) return;
+  double s = 0.0;
+  if ((e >> 6) < D && (e & 63) < D)
+    for (int b = 0; b < nblk; ++b) s += gpart[(int64_t)b * 4096 + e];
+  gram[e] = s;
+}
+
+// finalize, one workgroup of 16 waves per chain: fixed-order reduction over row blocks in double (a wave takes
+// every 16th row block; consecutive lanes read consecutive sums), undoing the power-of-two scales, the closed-form
+// correction for the part of W that its two f16 pieces do not hold (see the top of this file), S1 from the packed
+// data sums.
 constexpr int kFinGroups = 16;
 __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     const float* __restrict__ partials, const float* __restrict__ ublk, int cpb, int nb, int64_t n, int d,
     const unsigned char* __restrict__ packed, const float* __restrict__ theta, int C, float* __restrict__ logp,
     float* __restrict__ grad) {
-  const int q2 = d + 2, tot = C * q2;
+  const int c = blockIdx.x, q2 = d + 2;
+  const int64_t tot = (int64_t)C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
-  const int c = idx / q2, q = idx - c * q2;
   __shared__ double part[kFinGroups][64];
-  double s = 0.0;
-  if (idx < tot && q != 1) {
-#pragma unroll 4
-    for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + idx];
-  }
-  part[grp][o] = s;
-  __syncthreads();
-  if (grp != 0 || idx >= tot) return;
-  for (int w = 1; w < kFinGroups; ++w) s += part[w][o];
+  __shared__ double sums[66], dw[64], gc[64], corr[64];
   const Header* hdr = reinterpret_cast<const Header*>(packed);
+  const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
   const float* th = theta + (int64_t)c * q2;
-  const double u = (double)ublk[c / cpb];
-  if (q == 1) {
-    s = hdr->ysum - (double)n * (double)th[0];
-    for (int j = 0; j < d; ++j) s -= (double)th[1 + j] * hdr->colsum[j];
+  if (grp == 0) {
+    // dw_f = w_f - (what the kernel's two pieces of the scaled weight stand for), recomputed with the kernel's
+    // own arithmetic: w'' = -w / s_f * t, pieces hi + lo, remainder exact in f32
+    const float cs = o < d ? hdr->colscale[o] : 0.f;
+    const float v = o < d ? -scaled_weight(th[1 + o], cs) : 0.f;
+    float amax = fabsf(v);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    const float t = pow2_scale(amax);
+    const float q = v * t;
+    const _Float16 hi = (_Float16)q;
+    const _Float16 lo = (_Float16)(q - (float)hi);
+    const float rem = (q - (float)hi) - (float)lo;
+    dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;
   }
+  for (int q0 = 0; q0 < q2; q0 += 64) {
+    const int q = q0 + o;
+    double s = 0.0;
+    if (q < q2 && q != 1) {
+#pragma unroll 4
+      for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + (int64_t)c * q2 + q];
+    }
+    part[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && q < q2) {
+      for (int w = 1; w < kFinGroups; ++w) s += part[w][o];
+      sums[q] = s;
+    }
+    __syncthreads();
+  }
+  const double u = (double)ublk[c / cpb];
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
-  if (q == 0) {
-    s /= u * u;       // S2' = u^2 S2
-    logp[c] = (float)(-0.5 * s * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
-    if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s * inv2 / sc);
-  } else if (grad) {
-    if (q >= 2) {     // G'_d = u s_d G_d
-      const double cs = (double)hdr->colscale[q - 2];
-      s = cs > 0.0 ? s / (u * cs) : s * 0.0;
-    }
-    grad[(int64_t)c * q2 + (q - 1)] = (float)(s * inv2);
+  if (threadIdx.x < d) {
+    const int f = threadIdx.x;
+    const double cs = (double)hdr->colscale[f];
+    const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;   // G'_f = u s_f G_f
+    double cf = 0.0;
+    for (int g = 0; g < d; ++g) cf = fma(gram[g * 64 + f], dw[g], cf);          // (X^T X dw)_f, X^T X symmetric
+    gc[f] = g0;
+    corr[f] = cf;
+    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - cf) * inv2);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s2 = sums[0] / (u * u);       // S2' = u^2 S2
+    for (int f = 0; f < d; ++f) s2 += dw[f] * (corr[f] - 2.0 * gc[f]);
+    logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
+    if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
+  } else if (threadIdx.x == 64 && grad) {
+    double s1 = hdr->ysum - nn * (double)th[0];
+    for (int j = 0; j < d; ++j) s1 -= (double)th[1 + j] * hdr->colsum[j];
+    grad[(int64_t)c * q2] = (float)(s1 * inv2);
   }
 }
 
@@ -525,7 +612,8 @@ size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
 // scratch for the column statistics of the pack step (bytes)
 size_t bvi_linreg_f16_pack_scratch(int d) {
   const int dp = plane_cols(d);
-  return (size_t)kStatBlocks * (dp + 1) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) + 16;
+  return (size_t)kStatBlocks * (dp + 1) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
+         (size_t)kGramBlocks * 64 * 64 * sizeof(double) + 16;
 }
 
 int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,
@@ -536,7 +624,9 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   const int dp = plane_cols(d);
   const int64_t np = pad_rows(n);
   double* psum = (double*)scratch;
-  float* pmax = (float*)(psum + (size_t)kStatBlocks * (dp + 1));
+  double* gpart = psum + (size_t)kStatBlocks * (dp + 1);
+  float* pmax = (float*)(gpart + (size_t)kGramBlocks * 64 * 64);
+  double* gram = (double*)((unsigned char*)packed + kGramOffset);
   const int64_t total = np * (dp / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
@@ -546,12 +636,15 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
     hipLaunchKernelGGL(f16_header_kernel<64>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
                        kStatBlocks, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
+    hipLaunchKernelGGL(f16_gram_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
   } else {
     hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
     hipLaunchKernelGGL(f16_header_kernel<32>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
                        kStatBlocks, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
+    hipLaunchKernelGGL(f16_gram_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
   }
+  hipLaunchKernelGGL(f16_gram_final, dim3(16), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp, gram);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
@@ -579,8 +672,7 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   hipLaunchKernelGGL((linreg_f16_kernel<D, NW>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb,
                      ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
-  const int tot = c * (d + 2);
-  hipLaunchKernelGGL(linreg_f16_finalize, dim3(bvi_ceil_div(tot, 64)), dim3(64 * kFinGroups), 0, s, (const float*)ws,
+  hipLaunchKernelGGL(linreg_f16_finalize, dim3(c), dim3(64 * kFinGroups), 0, s, (const float*)ws,
                      (const float*)ublk, cpb, nrb, n, d, pk, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
