@@ -348,7 +348,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // A-operand ds_read_b128 (16 rows x two neighbouring chunks per lane group) is conflict-free; double buffered
   __shared__ __attribute__((aligned(16))) unsigned char ybuf[2][2][FT * 64];
   __shared__ float al[FW * KQ][FT];     // a_ik of the tile
-  __shared__ float ls[FT];              // log-sum-exp per row (+inf for rows past the end)
+  __shared__ float sq[FW * KQ][FT];     // sqrt(rho_ik) of the tile (0 for rows past the end)
+  __shared__ float cks[FW * KQ];        // the components' constants
   __shared__ float lpw[FT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -395,6 +396,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     cq[q] = kv ? cst[c * K + k] : -INFINITY;
   }
+
+  if (tid < FW * KQ) cks[tid] = tid < K ? cst[c * K + tid] : -INFINITY;   // visible after the barrier below
 
   f32x4 S2[KQ][2][2];
   float S1[KQ][2], S0[KQ];
@@ -487,15 +490,29 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
     __syncthreads();
-    if (tid < FT) {
+    {
+      // log-sum-exp of the row (every wave for all 64 rows: the redundancy is cheaper than a second barrier), then
+      // sqrt(rho_ik) = exp((a_ik - lse) / 2) for this wave's components, once per (row, component) instead of once
+      // per lane that needs it
+      const int row = lane;
       float m = -INFINITY;
-      for (int k = 0; k < K; ++k) m = fmaxf(m, al[k][tid]);
-      float s = 0.f;
-      for (int k = 0; k < K; ++k) s += __expf(al[k][tid] - m);
-      const float lse = m + __logf(s);
-      const bool valid = tile * FT + tid < n;
-      if (valid) logp_acc += lse;
-      ls[tid] = valid ? lse : INFINITY;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, al[k][row]);
+      float sm = 0.f;
+      for (int k = 0; k < K; ++k) sm += __expf(al[k][row] - m);
+      const float lse = m + __logf(sm);
+      const bool valid = tile * FT + row < n;
+      if (wave == 0 && valid) logp_acc += lse;
+      const float lsev = valid ? lse : INFINITY;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int k = wave + FW * q;
+        if (k < K) {
+          // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
+          // the gradient sums instead of turning them into NaN; its log-density is already counted
+          const float aik = al[k][row];
+          sq[k][row] = (aik > cks[k] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (aik - lsev));
+        }
+      }
     }
     __syncthreads();
     // ---- responsibilities and raw sums: w = sqrt(rho) u in two f16 pieces is both operand of S2 += W^T W ----
@@ -509,10 +526,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int row = 32 * m + 16 * (j >> 2) + 4 * g + (j & 3);
-            // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
-            // the gradient sums instead of turning them into NaN; its log-density is already counted
-            const float aik = al[k][row];
-            sr[j] = (aik > cq[q] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (aik - ls[row]));
+            sr[j] = sq[k][row];
             S0[q] = fmaf(sr[j], sr[j], S0[q]);
           }
           f16x8 wh[2], wl[2];
