@@ -78,6 +78,7 @@ def lib():
         l.bvi_posterior_assemble.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_leapfrog_pre.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp]
         l.bvi_leapfrog_post.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_leapfrog_mid.argtypes = [bp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_leapfrog_pre_chainwise.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp]
         l.bvi_leapfrog_post_chainwise.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         nsp = ctypes.POINTER(NutsState)
@@ -97,7 +98,7 @@ def lib():
         l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
         for name in ('bvi_constrain', 'bvi_posterior_assemble', 'bvi_leapfrog_pre', 'bvi_leapfrog_post',
                      'bvi_hmc_begin', 'bvi_hmc_end', 'bvi_hmc_fused', 'bvi_nuts_fused', 'bvi_rwm_fused', 'bvi_philox_uint32', 'bvi_philox_normal',
-                     'bvi_leapfrog_pre_chainwise', 'bvi_leapfrog_post_chainwise', 'bvi_nuts_begin',
+                     'bvi_leapfrog_mid', 'bvi_leapfrog_pre_chainwise', 'bvi_leapfrog_post_chainwise', 'bvi_nuts_begin',
                      'bvi_nuts_subtree_begin', 'bvi_nuts_leaf', 'bvi_nuts_subtree_end'):
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',

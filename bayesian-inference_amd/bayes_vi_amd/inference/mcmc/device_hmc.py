@@ -51,12 +51,15 @@ class DeviceHamiltonianMonteCarloKernel:
                                         ptr(b['p']), ptr(b['z0']), ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']),
                                         ptr(step_offset), st), 'bvi_hmc_begin')
         lik = self.posterior.likelihood
-        for _ in range(self.num_leapfrog_steps):
-            _native.check(lib.bvi_leapfrog_pre(self.blocks, self.nb, c, eps, ptr(z), ptr(b['p']), ptr(g),
-                                               ptr(b['theta']), st), 'bvi_leapfrog_pre')
+        _native.check(lib.bvi_leapfrog_pre(self.blocks, self.nb, c, eps, ptr(z), ptr(b['p']), ptr(g),
+                                           ptr(b['theta']), st), 'bvi_leapfrog_pre')
+        for i in range(self.num_leapfrog_steps):
             ll, gl = lik.logp_grad(b['theta'], True)          # fused data pass (+ all-reduce over row shards)
-            _native.check(lib.bvi_leapfrog_post(self.blocks, self.nb, c, eps, ptr(z), ptr(b['p']), ptr(b['theta']),
-                                                ptr(ll), ptr(gl), ptr(lp), ptr(g), st), 'bvi_leapfrog_post')
+            # interior steps: the second half of this step and the first half of the next in one launch
+            last = i + 1 == self.num_leapfrog_steps
+            fn, name = (lib.bvi_leapfrog_post, 'bvi_leapfrog_post') if last else (lib.bvi_leapfrog_mid, 'bvi_leapfrog_mid')
+            _native.check(fn(self.blocks, self.nb, c, eps, ptr(z), ptr(b['p']), ptr(b['theta']), ptr(ll), ptr(gl),
+                             ptr(lp), ptr(g), st), name)
         _native.check(lib.bvi_hmc_end(c, pu, seed, step,
                                       ptr(log_uniform.contiguous()) if log_uniform is not None else None,
                                       ptr(z), ptr(g), ptr(lp), ptr(b['p']), ptr(b['z0']), ptr(b['g0']),

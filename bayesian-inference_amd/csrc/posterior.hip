@@ -250,6 +250,22 @@ __global__ __launch_bounds__(1024) void leapfrog_post_kernel(Blocks bl, int C, i
                                 nullptr, theta + (int64_t)c * P, ll, gl + (int64_t)c * P, lp, g + (int64_t)c * Pu, c, red);
 }
 
+// leapfrog "post" of one step and "pre" of the next in one launch (interior steps of a trajectory):
+// lp, g = assemble at z; p += eps g (two half steps); z += eps p; theta = f(z)
+__global__ __launch_bounds__(1024) void leapfrog_mid_kernel(Blocks bl, int C, int P, int Pu, float eps,
+                                                            float* __restrict__ z, float* __restrict__ p,
+                                                            float* __restrict__ theta, const float* __restrict__ ll,
+                                                            float* __restrict__ gl, float* __restrict__ lp,
+                                                            float* __restrict__ g) {
+  const int c = blockIdx.x;
+  __shared__ float red[16];
+  chain_work<false, true, true>(bl, P, Pu, eps, z + (int64_t)c * Pu, p + (int64_t)c * Pu, nullptr,
+                                theta + (int64_t)c * P, ll, gl + (int64_t)c * P, lp, g + (int64_t)c * Pu, c, red);
+  __syncthreads();     // the gradient and momentum written above are read back below (by the same threads)
+  chain_work<true, false, false>(bl, P, Pu, eps, z + (int64_t)c * Pu, p + (int64_t)c * Pu, g + (int64_t)c * Pu,
+                                 theta + (int64_t)c * P, nullptr, nullptr, nullptr, nullptr, c, red);
+}
+
 // HMC begin: save the current state, draw (or copy) momenta, record the initial kinetic energy.
 // One workgroup per chain; a thread owns whole Philox blocks (4 consecutive elements).
 __global__ __launch_bounds__(1024) void hmc_begin_kernel(int C, int Pu, uint64_t seed, uint64_t step,
@@ -406,6 +422,19 @@ int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains,
                       void* stream) {
   return launch_post(blocks, n_blocks, n_chains, step_size, nullptr, z, p, theta, loglik, grad_theta, lp, grad_z,
                      stream);
+}
+
+int bvi_leapfrog_mid(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, float* z, float* p,
+                     float* theta, const float* loglik, float* grad_theta, float* lp, float* grad_z, void* stream) {
+  Blocks bl;
+  int P, Pu;
+  const int st = make_blocks(blocks, n_blocks, &bl, &P, &Pu, true);
+  if (st != BVI_OK) return st;
+  if (!z || !p || !theta || !loglik || !grad_theta || !lp || !grad_z || n_chains < 1) return BVI_ERR_ARG;
+  hipLaunchKernelGGL(leapfrog_mid_kernel, dim3(n_chains), dim3(chain_threads(P)), 0, (hipStream_t)stream, bl, n_chains,
+                     P, Pu, step_size, z, p, theta, loglik, grad_theta, lp, grad_z);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
 }
 
 int bvi_leapfrog_pre_chainwise(const bvi_param_block* blocks, int n_blocks, int n_chains, const float* step_sizes,

@@ -197,6 +197,10 @@ int bvi_leapfrog_pre(const bvi_param_block* blocks, int n_blocks, int n_chains, 
 int bvi_leapfrog_post(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
                       const float* z, float* p, float* theta, const float* loglik, float* grad_theta, float* lp,
                       float* grad_z, void* stream);
+/* post of one leapfrog step and pre of the next in one launch (the interior steps of a trajectory):
+ * same arguments as bvi_leapfrog_post, z and theta are updated as by bvi_leapfrog_pre. */
+int bvi_leapfrog_mid(const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size, float* z, float* p,
+                     float* theta, const float* loglik, float* grad_theta, float* lp, float* grad_z, void* stream);
 int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step, const float* z,
                   const float* grad_z, const float* lp, const float* momenta_in, float* p, float* z0, float* g0,
                   float* lp0, float* k0, const uint64_t* step_offset, void* stream);
