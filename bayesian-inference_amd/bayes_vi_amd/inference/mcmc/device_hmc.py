@@ -422,3 +422,83 @@ class BatchedDeviceNoUTurnSamplerKernel:
                  'step_size': torch.full((), self.step_size, dtype=z.dtype), 'leapfrogs_taken': n_leap,
                  'has_divergence': (fl & _native.NUTS_DIVERGED) != 0, 'energy': -lp}
         return z, {'target_log_prob': lp, 'grad': g}, trace
+
+
+class DeviceRandomWalkMetropolisKernel:
+    """Random-walk Metropolis (tfp.mcmc.RandomWalkMetropolis with the default N(0, scale^2) proposal,
+    bayes_vi/inference/mcmc/transition_kernels.py:319-321) for datasets beyond the one-workgroup-per-chain
+    kernel, composed from the HMC entry points: bvi_hmc_begin saves the state and draws the step p,
+    bvi_leapfrog_pre with a zero gradient and step size `scale` moves z += scale p and constrains,
+    the value-only data pass and bvi_posterior_assemble give log pi at the proposal, and bvi_hmc_end
+    accepts on log pi' - log pi (p is unchanged, so its kinetic terms cancel) and restores rejected chains.
+    Same Philox draws as `FusedRandomWalkMetropolisKernel`; nothing synchronises with the host."""
+    trace_names = ('is_accepted',)
+    supports_many_steps = True
+
+    def __init__(self, posterior, scale=1.0, seed=0):
+        self.posterior = posterior
+        self.blocks = posterior.device_blocks()
+        if self.blocks is None:
+            raise _native.BviError('this model has priors/bijectors outside the device-side posterior assembly')
+        self.nb = len(self.blocks)
+        self.scale = float(scale)
+        self.seed = int(seed)
+        self.transition = 0
+        self._bufs = None
+
+    def _buffers(self, z):
+        c, pu = z.shape
+        if self._bufs is None or self._bufs['p'].shape != z.shape:
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=z.device)
+            self._bufs = dict(p=f(c, pu), z0=f(c, pu), g0=f(c, pu), lp0=f(c), k0=f(c), lr=f(c),
+                              gzero=torch.zeros(c, pu, dtype=torch.float32, device=z.device),
+                              theta=f(c, self.posterior.n_constrained),
+                              acc=torch.empty(c, dtype=torch.uint8, device=z.device))
+        return self._bufs
+
+    def bootstrap(self, z):
+        lp, _ = self.posterior.unconstrained_log_prob_and_grad(z, False)
+        return {'target_log_prob': lp.contiguous()}
+
+    def _transition(self, z, lp, b, seed, step):
+        lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
+        c, pu = z.shape
+        g = b['gzero']
+        _native.check(lib.bvi_hmc_begin(c, pu, seed, step, ptr(z), ptr(g), ptr(lp), None, ptr(b['p']), ptr(b['z0']),
+                                        ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']), None, st), 'bvi_hmc_begin')
+        _native.check(lib.bvi_leapfrog_pre(self.blocks, self.nb, c, self.scale, ptr(z), ptr(b['p']), ptr(g),
+                                           ptr(b['theta']), st), 'bvi_leapfrog_pre')
+        ll, _ = self.posterior.likelihood.logp_grad(b['theta'], False)
+        _native.check(lib.bvi_posterior_assemble(self.blocks, self.nb, c, ptr(z), ptr(b['theta']), ptr(ll), None,
+                                                 ptr(lp), None, st), 'bvi_posterior_assemble')
+        _native.check(lib.bvi_hmc_end(c, pu, seed, step, None, ptr(z), ptr(g), ptr(lp), ptr(b['p']), ptr(b['z0']),
+                                      ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']), ptr(b['acc']), ptr(b['lr']), None,
+                                      st), 'bvi_hmc_end')
+
+    def one_step(self, z, state, generator=None):
+        z = z.clone().contiguous()
+        lp = state['target_log_prob'].clone()
+        b = self._buffers(z)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        self._transition(z, lp, b, seed, self.transition)
+        self.transition += 1
+        return z, {'target_log_prob': lp}, {'is_accepted': b['acc'].to(torch.bool),
+                                             'log_accept_ratio': b['lr'].clone()}
+
+    def many_steps(self, z, state, n, generator=None):
+        z = z.clone().contiguous()
+        lp = state['target_log_prob'].clone()
+        c, pu = z.shape
+        b = self._buffers(z)
+        zs = torch.empty(n, c, pu, dtype=torch.float32, device=z.device)
+        accs = torch.empty(n, c, dtype=torch.uint8, device=z.device)
+        lrs = torch.empty(n, c, dtype=torch.float32, device=z.device)
+        seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
+        for t in range(n):
+            self._transition(z, lp, b, seed, self.transition + t)
+            zs[t].copy_(z)
+            accs[t].copy_(b['acc'])
+            lrs[t].copy_(b['lr'])
+        self.transition += n
+        return zs, z, {'target_log_prob': lp}, {'is_accepted': accs.to(torch.bool), 'log_accept_ratio': lrs}
+

@@ -106,8 +106,11 @@ class RandomWalkMetropolis(TransitionKernel):
         post = getattr(target, '__self__', None)
         if self.new_state_fn is None and post is not None and hasattr(post, 'device_blocks') \
                 and post.likelihood.device.type == 'cuda':
-            from .device_hmc import FusedRandomWalkMetropolisKernel, fused_family
+            from .device_hmc import (DeviceRandomWalkMetropolisKernel, FusedRandomWalkMetropolisKernel,
+                                     fused_family)
             fam = fused_family(post)
             if fam is not None:     # small dataset, default proposal: whole runs of transitions per launch
                 return FusedRandomWalkMetropolisKernel(post, fam)
+            if post.device_blocks() is not None:    # any size: propose / accept on the stream, no host sync
+                return DeviceRandomWalkMetropolisKernel(post)
         return samplers.RandomWalkMetropolisKernel(target, new_state_fn=self.new_state_fn)

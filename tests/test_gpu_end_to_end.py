@@ -439,6 +439,40 @@ def test_fused_rwm_kernel_follows_oracle(bvi, gpu_device):
         assert checked > 0.8 * 25 * c
 
 
+def test_device_rwm_kernel_gives_the_chain_of_the_fused_kernel(bvi, gpu_device):
+    """DeviceRandomWalkMetropolisKernel (begin / pre with zero gradient / value-only pass / assemble / end)
+    draws the same Philox proposals and uniforms as bvi_rwm_fused, which is checked against the oracle
+    above: both must make the same decisions and visit the same positions."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import (DeviceRandomWalkMetropolisKernel,
+                                                        FusedRandomWalkMetropolisKernel, fused_family)
+    rng = np.random.default_rng(43)
+    for name, model, ds, spec, z in _fused_cases(bvi, rng):
+        post = bvi.MCMC(model, ds).posterior
+        scale = {'normal': 0.3, 'linreg': 0.01, 'gmm1d': 0.03}[name]
+        zt = torch.tensor(z.astype(np.float32), device=gpu_device)
+        fused = FusedRandomWalkMetropolisKernel(post, fused_family(post), scale=scale, seed=13)
+        zs_f, _, _, tr_f = fused.many_steps(zt, fused.bootstrap(zt), 25)
+        dev_k = DeviceRandomWalkMetropolisKernel(post, scale=scale, seed=13)
+        zs_d, zf, stf, tr_d = dev_k.many_steps(zt, dev_k.bootstrap(zt), 25)
+        lr_f, lr_d = tr_f['log_accept_ratio'].cpu().numpy(), tr_d['log_accept_ratio'].cpu().numpy()
+        acc_f, acc_d = tr_f['is_accepted'].cpu().numpy(), tr_d['is_accepted'].cpu().numpy()
+        # a decision can only differ where the float32 log ratios of the two evaluation orders straddle log u;
+        # after such a split the chains differ, so compare chain by chain up to the first disagreement
+        agree = 0
+        for ch in range(z.shape[0]):
+            for t in range(25):
+                if acc_f[t, ch] != acc_d[t, ch]:
+                    assert abs(lr_f[t, ch] - lr_d[t, ch]) < 5e-3, (name, ch, t)
+                    break
+                np.testing.assert_allclose(zs_d[t, ch].cpu().numpy(), zs_f[t, ch].cpu().numpy(), rtol=1e-5, atol=1e-5)
+                assert abs(lr_f[t, ch] - lr_d[t, ch]) < 5e-3 + 1e-4 * abs(lr_f[t, ch]), (name, ch, t)
+                agree += 1
+        assert agree > 0.8 * 25 * z.shape[0], (name, agree)
+        assert 0 < acc_d.mean() < 1
+        z1, st1, tr1 = dev_k.one_step(zf, stf)      # continues the chain; the caller's tensors are untouched
+        assert z1.shape == zf.shape and tr1['is_accepted'].dtype == torch.bool
+
+
 def test_fused_nuts_kernel_follows_oracle_transition_by_transition(bvi, gpu_device):
     """bvi_nuts_fused against oracle/nuts.py, which draws the same Philox numbers: every transition of
     a 40-transition launch is replayed by the oracle from the device's own previous state and must give
@@ -546,6 +580,9 @@ def test_batched_device_nuts_through_mcmc_fit_on_a_large_regression(bvi, gpu_dev
     mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=cfg)
     kernel, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
     assert isinstance(kernel.inner, BatchedDeviceNoUTurnSamplerKernel)
+    from bayes_vi_amd.inference.mcmc.device_hmc import DeviceRandomWalkMetropolisKernel
+    rwm = bvi.RandomWalkMetropolis()(mcmc.posterior.unconstrained_log_prob_and_grad)[0]
+    assert isinstance(getattr(rwm, 'inner', rwm), DeviceRandomWalkMetropolisKernel)
     A = np.concatenate([X.astype(np.float64), np.ones((n, 1))], 1)
     ols = np.linalg.lstsq(A, y.astype(np.float64), rcond=None)[0]
     init = [torch.full((4,), float(ols[d])), torch.tensor(np.tile(ols[:d], (4, 1)), dtype=torch.float32),
