@@ -559,6 +559,38 @@ def test_batched_device_nuts_follows_oracle_transition_by_transition(bvi, gpu_de
         assert len(sizes) >= 2, (name, sizes)      # chains did stop at different tree sizes
 
 
+def test_device_nuts_kernels_survive_divergent_trajectories(bvi, gpu_device):
+    """A step size far too large: trajectories blow up (energy error beyond max_energy_diff, non-finite
+    densities).  Both NUTS forms must flag the divergence, keep every chain at a finite state whose cached
+    log density is the density of that state, and go on sampling afterwards."""
+    from bayes_vi_amd.inference.mcmc.device_hmc import (BatchedDeviceNoUTurnSamplerKernel,
+                                                        FusedNoUTurnSamplerKernel, fused_family)
+    rng = np.random.default_rng(5)
+    y = rng.normal(7, 3, 20).astype(np.float32)
+    model, ds = normal_setup(bvi, y)
+    post = bvi.MCMC(model, ds).posterior
+    spec = cf.normal_model(y)
+    z0 = torch.tensor(rng.uniform(-.5, .5, (6, 2)) + np.array([6.0, 1.5]), dtype=torch.float32, device=gpu_device)
+    for kern in (BatchedDeviceNoUTurnSamplerKernel(post, step_size=40.0, max_tree_depth=5, seed=3),
+                 FusedNoUTurnSamplerKernel(post, fused_family(post), step_size=40.0, max_tree_depth=5, seed=3)):
+        z, st = z0, kern.bootstrap(z0)
+        diverged = 0
+        for t in range(12):
+            z, st, tr = kern.one_step(z, st)
+            diverged += int(tr['has_divergence'].sum())
+            assert bool(torch.isfinite(z).all()) and bool(torch.isfinite(st['target_log_prob']).all())
+            ref_lp, _ = spec.log_post_unconstrained(z.cpu().numpy().astype(np.float64))
+            np.testing.assert_allclose(st['target_log_prob'].cpu().numpy(), ref_lp, rtol=2e-5, atol=2e-3)
+            assert int(tr['leapfrogs_taken'].min()) >= 1
+        assert diverged > 0, type(kern).__name__
+        kern.step_size = 0.2                       # back to a sane step: the chains move again
+        moved = 0
+        for t in range(10):
+            z, st, tr = kern.one_step(z, st)
+            moved += int(tr['is_accepted'].sum())
+        assert moved > 20 and not bool(tr['has_divergence'].any())
+
+
 def test_batched_device_nuts_through_mcmc_fit_on_a_large_regression(bvi, gpu_device):
     """A regression too large for the one-workgroup-per-chain kernel: MCMC.fit selects the batched device
     NUTS; posterior moments against the exact conjugate answer (flat-ish priors, known noise scale is
