@@ -18,6 +18,7 @@ PACK_BF16X3, PACK_F16 = 0, 1
 BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED, BIJ_FILL_SCALE_TRIL = 0, 1, 2, 3, 4
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
+ABI_VERSION = 101     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -62,6 +63,9 @@ def lib():
         l = ctypes.CDLL(_LIB_PATH)
         vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
         l.bvi_version.restype = i32
+        if l.bvi_version() != ABI_VERSION:
+            raise BviError('libbvi_hip.so at %s has ABI version %d, this binding needs %d -- rebuild it with '
+                           '`make -C bayesian-inference_amd/csrc`' % (_LIB_PATH, l.bvi_version(), ABI_VERSION))
         l.bvi_status_string.restype = ctypes.c_char_p
         l.bvi_status_string.argtypes = [i32]
         l.bvi_workspace_bytes.argtypes = [i32, i64, i32, i32, i32, ctypes.POINTER(sz)]

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 100
+#define BVI_VERSION 101
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
