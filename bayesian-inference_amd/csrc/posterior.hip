@@ -75,6 +75,49 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
     return z[i];
   };
   float part = 0.f;      // this lane's share of log prior + fldj
+  // All blocks whose bijector acts element by element (identity, softplus, exp) in ONE sweep over the flat
+  // parameter vector -- a thread finds the block of its element by a scan of the (at most 16) block sizes --
+  // so that the loads of the whole vector are in flight together instead of block after block.
+  for (int t = lane; t < P; t += nt) {
+    int i = 0, bo_t = 0, bo_z = 0;
+    for (; i < bl.n - 1; ++i) {
+      if (t < bo_t + bl.b[i].size) break;
+      bo_t += bl.b[i].size;
+      bo_z += usize_of(bl.b[i]);
+    }
+    const bvi_param_block b = bl.b[i];
+    if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED || b.bijector == BVI_BIJ_FILL_SCALE_TRIL) continue;
+    const int zi = bo_z + (t - bo_t);
+    const float x = zval(zi);
+    float th, fl = 0.f, dth = 1.f, dfl = 0.f;   // theta, fldj share, d theta / dx, d fldj / dx
+    if (b.bijector == BVI_BIJ_SOFTPLUS) {
+      th = softplusf(x); fl = -softplusf(-x); dth = sigmoidf(x); dfl = sigmoidf(-x);
+    } else if (b.bijector == BVI_BIJ_EXP) {
+      th = expf(x); fl = x; dth = th; dfl = 1.f;
+    } else {
+      th = x;
+    }
+    theta[t] = th;
+    if (ASSEMBLE) {
+      float sc;
+      part += fl + prior_elem(b, t - bo_t, th, &sc);
+      if (gl) {
+        const float gt = gl[t] + sc;
+        gl[t] = gt;
+        if (gz) {
+          const float gzj = fmaf(gt, dth, dfl);
+          gz[zi] = gzj;
+          if (HALFSTEP) p[zi] = fmaf(0.5f * eps, gzj, p[zi]);
+        }
+      }
+    }
+    if (PRE) {         // this thread owns the element: update it in place
+      const float pj = fmaf(0.5f * eps, g_old[zi], p[zi]);
+      p[zi] = pj;
+      z[zi] = x;
+    }
+  }
+  // blocks that need the whole block at once (softmax: reductions; triangular fill: index map)
   int oz = 0, ot = 0;
   for (int i = 0; i < bl.n; ++i) {
     const bvi_param_block b = bl.b[i];
@@ -150,37 +193,6 @@ __device__ void chain_work(const Blocks& bl, int P, int Pu, float eps, float* __
           const float pj = fmaf(0.5f * eps, g_old[src], p[src]);
           p[src] = pj;
           z[src] = x;
-        }
-      }
-    } else {
-      for (int j = lane; j < b.size; j += nt) {
-        const float x = zval(oz + j);
-        float th, fl = 0.f, dth = 1.f, dfl = 0.f;   // theta, fldj share, d theta / dx, d fldj / dx
-        if (b.bijector == BVI_BIJ_SOFTPLUS) {
-          th = softplusf(x); fl = -softplusf(-x); dth = sigmoidf(x); dfl = sigmoidf(-x);
-        } else if (b.bijector == BVI_BIJ_EXP) {
-          th = expf(x); fl = x; dth = th; dfl = 1.f;
-        } else {
-          th = x;
-        }
-        theta[ot + j] = th;
-        if (ASSEMBLE) {
-          float sc;
-          part += fl + prior_elem(b, j, th, &sc);
-          if (gl) {
-            const float gt = gl[ot + j] + sc;
-            gl[ot + j] = gt;
-            if (gz) {
-              const float gzj = fmaf(gt, dth, dfl);
-              gz[oz + j] = gzj;
-              if (HALFSTEP) p[oz + j] = fmaf(0.5f * eps, gzj, p[oz + j]);
-            }
-          }
-        }
-        if (PRE) {         // this lane owns element j: update it in place
-          const float pj = fmaf(0.5f * eps, g_old[oz + j], p[oz + j]);
-          p[oz + j] = pj;
-          z[oz + j] = x;
         }
       }
     }
