@@ -3,10 +3,11 @@
 // tfp.mcmc.NoUTurnSampler (bayes_vi/inference/mcmc/transition_kernels.py:238-246) -- direction and
 // subtree set-up, energy and divergence test, multinomial sampling inside the subtree, checkpointed
 // U-turn checks, biased progressive sampling between subtrees, the stopping rule -- runs on the device,
-// one workgroup per chain (64 to 1024 threads, by the size of the parameter vector), threads over its elements.  The host only sequences the launches
+// one workgroup per chain (64 to 1024 threads, by the size of the parameter vector), threads over its
+// elements.  The host only sequences the launches
 //   begin; per depth { subtree_begin; per leaf { leapfrog_pre_chainwise, <family>_logp_grad
 //   [, all-reduce], leapfrog_post_chainwise, leaf }; subtree_end }
-// and reads one word per leaf / depth to learn whether any chain is still building / still active.
+// and reads one word per second leaf / per depth to learn whether any chain is still building / active.
 // Chains advance in lock-step; a chain that is done gets step size 0 (bvi_nuts_state.se), which freezes
 // it, and is ignored by the bookkeeping.  Same algorithm and the same Philox draws as the
 // one-workgroup-per-chain kernel in hmc_fused.hip (momenta: stream 0; direction / subtree-accept
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(1024) void nuts_leaf_kernel(bvi_nuts_state s, uint6
     for (int k = lo; k <= hi; ++k) {
       const float* cq = s.ck_q + ((int64_t)k * C + c) * Pu;
       const float* cp = s.ck_p + ((int64_t)k * C + c) * Pu;
-      const bool tn = go_right ? nb_turning(cq, cp, s.q + o, s.p + o, Pu, red) : nb_turning(s.q + o, s.p + o, cq, cp, Pu, red);
+      const bool tn = go_right ? nb_turning(cq, cp, s.q + o, s.p + o, Pu, red)
+                               : nb_turning(s.q + o, s.p + o, cq, cp, Pu, red);
       turn |= ok && tn;
     }
   }
@@ -179,6 +181,8 @@ __global__ __launch_bounds__(1024) void nuts_subtree_end_kernel(bvi_nuts_state s
   }
 }
 
+dim3 chain_block(const bvi_nuts_state* s) { return dim3(chain_threads(s->n_unconstrained)); }
+
 int check_state(const bvi_nuts_state* s) {
   if (!s || s->n_chains < 1 || s->n_unconstrained < 1 || s->max_tree_depth < 1 || s->max_tree_depth > 10 ||
       !(s->max_energy_diff > 0.f))
@@ -198,7 +202,8 @@ extern "C" {
 int bvi_nuts_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, void* stream) {
   const int st = check_state(state);
   if (st != BVI_OK) return st;
-  hipLaunchKernelGGL(nuts_begin_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state, seed, step);
+  hipLaunchKernelGGL(nuts_begin_kernel, dim3(state->n_chains), chain_block(state), 0, (hipStream_t)stream, *state,
+                     seed, step);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
@@ -207,8 +212,9 @@ int bvi_nuts_subtree_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t 
   const int st = check_state(state);
   if (st != BVI_OK) return st;
   if (depth < 0 || depth >= state->max_tree_depth) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(nuts_subtree_begin_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state, seed,
-                     step, depth);
+  hipLaunchKernelGGL(nuts_subtree_begin_kernel, dim3(state->n_chains), chain_block(state), 0, (hipStream_t)stream,
+                     *state,
+                     seed, step, depth);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
@@ -218,8 +224,8 @@ int bvi_nuts_leaf(const bvi_nuts_state* state, uint64_t seed, uint64_t step, int
   const int st = check_state(state);
   if (st != BVI_OK) return st;
   if (leaf < 0 || !any_building) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(nuts_leaf_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state, seed, step,
-                     leaf, any_building);
+  hipLaunchKernelGGL(nuts_leaf_kernel, dim3(state->n_chains), chain_block(state), 0, (hipStream_t)stream, *state,
+                     seed, step, leaf, any_building);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
@@ -228,7 +234,8 @@ int bvi_nuts_subtree_end(const bvi_nuts_state* state, int* any_active, void* str
   const int st = check_state(state);
   if (st != BVI_OK) return st;
   if (!any_active) return BVI_ERR_ARG;
-  hipLaunchKernelGGL(nuts_subtree_end_kernel, dim3(state->n_chains), dim3(chain_threads(state->n_unconstrained)), 0, (hipStream_t)stream, *state,
+  hipLaunchKernelGGL(nuts_subtree_end_kernel, dim3(state->n_chains), chain_block(state), 0, (hipStream_t)stream,
+                     *state,
                      any_active);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;

@@ -59,7 +59,8 @@ __device__ __forceinline__ float prior_elem(const bvi_param_block& b, int j, flo
   return 0.f;
 }
 
-// The work of one chain (one workgroup; `red` = __shared__ float[16] for its reductions).  PRE: the position the constraint is applied to is
+// The work of one chain (one workgroup; `red` = __shared__ float[16] for its reductions).
+// PRE: the position the constraint is applied to is
 // z + eps (p + eps/2 g), formed on the fly from the old z, p, g (which are updated in place afterwards).
 // ASSEMBLE: also priors, fldj, chain rule (gl gets the prior score added in place, gz is written);
 // HALFSTEP: then p += eps/2 gz.  Every in-place update is made by the lane that owns the element,
@@ -468,7 +469,8 @@ int bvi_hmc_begin(int n_chains, int n_unconstrained, uint64_t seed, uint64_t ste
                   float* lp0, float* k0, const uint64_t* step_offset, void* stream) {
   if (!z || !grad_z || !lp || !p || !z0 || !g0 || !lp0 || !k0 || n_chains < 1 || n_unconstrained < 1)
     return BVI_ERR_ARG;
-  hipLaunchKernelGGL(hmc_begin_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream, n_chains,
+  hipLaunchKernelGGL(hmc_begin_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream,
+                     n_chains,
                      n_unconstrained, seed, step, z, grad_z, lp, momenta_in, p, z0, g0, lp0, k0, step_offset);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
@@ -481,7 +483,8 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
   if (!z || !grad_z || !lp || !p || !z0 || !g0 || !lp0 || !k0 || !is_accepted || !log_accept_ratio ||
       n_chains < 1 || n_unconstrained < 1)
     return BVI_ERR_ARG;
-  hipLaunchKernelGGL(hmc_end_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream, n_chains,
+  hipLaunchKernelGGL(hmc_end_kernel, dim3(n_chains), dim3(chain_threads(n_unconstrained)), 0, (hipStream_t)stream,
+                     n_chains,
                      n_unconstrained, seed, step, log_u_in, z, grad_z, lp, p, z0, g0, lp0, k0, is_accepted,
                      log_accept_ratio, step_offset);
   BVI_HIP_CHECK_LAUNCH();
