@@ -104,7 +104,7 @@ __device__ __forceinline__ void split_pair(float q0, float q1, unsigned& hi, uns
       : "v"(q0), "v"(q1));
 }
 
-template <int D, int NW>
+template <int D, int NW, int CT>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_kernel(
     const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
     int nrb, float* __restrict__ partials, float* __restrict__ ublk) {
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int ln = lane & 15, g = lane >> 4;
   const int x8 = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
-  const int cbase = cbi * (32 * NW) + 32 * wave;
+  // CT chain tiles of 16 per wave: 2 for the many-chain shapes, 1 when at most 16 NW chains are asked for
+  const int cbase = cbi * (16 * CT * NW) + 16 * CT * wave;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
   const int64_t n_pad = ntiles * kTileRows;
@@ -136,13 +137,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
 
   // scaled -W fragments in two f16 pieces; per chain: c1 = u / t and nb0 = -b0
-  f16x8 w1[2][KS], w2[2][KS];
-  float nb0[2], c1[2];
+  f16x8 w1[CT][KS], w2[CT][KS];
+  float nb0[CT], c1[CT];
   float u;
   {
     float umin = INFINITY;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       const int chain = cbase + 16 * ct + ln;
       const bool cvalid = chain < C;
       const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
@@ -179,19 +180,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     u = sh_u[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) u = fminf(u, sh_u[w]);
-    c1[0] *= u;
-    c1[1] *= u;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) c1[ct] *= u;
     if (rbi == 0 && tid == 0) ublk[cbi] = u;
   }
 
-  f32x4v G[2][FT];
+  f32x4v G[CT][FT];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int i = 0; i < 4; ++i) G[ct][ft][i] = 0.f;
-  float s2[2] = {0.f, 0.f};
+  float s2[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) s2[ct] = 0.f;
 
   // chunk q of row r lives at chunk q ^ swz(r): with it the A-operand ds_read_b128 (lane groups
   // {0-3,12-15,20-27}, ...: 16 rows, two neighbouring chunks), the transposed ds_read_b64_tr_b16 (32 lanes:
@@ -241,11 +244,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     gload(tile + nrb);   // past the end: re-reads tile 0, never used
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* base = lds + buf * BUF;
-    float a2[2] = {0.f, 0.f};   // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
+    float a2[CT];               // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) a2[ct] = 0.f;
 #pragma unroll
     for (int sub = 0; sub < kTileRows / 64; ++sub) {
     const int ro = 64 * sub;
-    f32x4v Z[4][2];
+    f32x4v Z[4][CT];
     // LDS fragments are fetched one step ahead of the MFMAs that consume them (the scheduler
     // barriers keep the fetches where they are written), so that their latency is not exposed
     f16x8 ah[2][KS], al[2][KS];
@@ -278,31 +283,31 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (rt < 3) load_a(rt + 1, (rt + 1) & 1);
       else { load_x(0, 0, 0); load_x(0, 1, 1); }
       __builtin_amdgcn_sched_barrier(0);
-      f32x4v z[2];
+      f32x4v z[CT];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int i = 0; i < 4; ++i) z[ct][i] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w2[ct][ks], z[ct], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int i = 0; i < 4; ++i) Z[rt][ct][i] = fmaf(z[ct][i], c1[ct], fmaf(mv[i], nb0[ct], yv[i]));
     }
     // GEMM2: G' += R'^T X' over the two 32-row pairs
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      f16x8 rh[2], rl[2];
+      f16x8 rh[CT], rl[CT];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (step + 2 < 2 * FT) load_x((step + 2) / FT, (step + 2) % FT, (step + 2) % 3);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ct], xh[cur], G[ct][ft], 0, 0, 0);
           G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl[ct], xh[cur], G[ct][ft], 0, 0, 0);
           G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ct], xl[cur], G[ct][ft], 0, 0, 0);
@@ -329,15 +334,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
     }
-    s2[0] += a2[0];
-    s2[1] += a2[1];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) s2[ct] += a2[ct];
     lstore(buf ^ 1);     // as late as possible: the whole tile's arithmetic covers the HBM latency of gload
     __syncthreads();
     buf ^= 1;
   }
 
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     float v = s2[ct];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -649,10 +654,10 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   return BVI_OK;
 }
 
-template <int D, int NW>
+template <int D, int NW, int CT>
 static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* theta, int c, float* logp, float* grad,
                       float* ws, hipStream_t s) {
-  constexpr int cpb = 32 * NW;
+  constexpr int cpb = 16 * CT * NW;
   // NW = 8: one workgroup per CU; NW = 4 (at most 128 chains): two per CU, each on its own row blocks
   constexpr int max_blocks = NW == 8 ? kMaxRowBlocks : 2 * kMaxRowBlocks;
   const int ncb = bvi_ceil_div(c, cpb);
@@ -664,12 +669,12 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * D + 2 * kTileRows * 4);
   static bool lds_ok = false;                 // > 64 KB of dynamic LDS has to be allowed once per kernel
   if (!lds_ok) {
-    hipError_t e = hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW>,
+    hipError_t e = hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW, CT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     lds_ok = true;
   }
-  hipLaunchKernelGGL((linreg_f16_kernel<D, NW>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb,
+  hipLaunchKernelGGL((linreg_f16_kernel<D, NW, CT>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb,
                      ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(linreg_f16_finalize, dim3(c), dim3(64 * kFinGroups), 0, s, (const float*)ws,
@@ -683,11 +688,17 @@ int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* the
   if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
   const unsigned char* pk = (const unsigned char*)packed;
-  // above 128 chains the 8-wave workgroup wins: every tile is fetched from L2 by half as many workgroups
-  // (measured at 1024 chains: 6.5 ms against 7.1 ms)
-  const bool wide = plane_cols(d) == 64, few = c <= 128;
-  if (wide) return few ? launch_f16<64, 4>(pk, n, d, theta, c, logp, grad, ws, s)
-                       : launch_f16<64, 8>(pk, n, d, theta, c, logp, grad, ws, s);
-  return few ? launch_f16<32, 4>(pk, n, d, theta, c, logp, grad, ws, s)
-             : launch_f16<32, 8>(pk, n, d, theta, c, logp, grad, ws, s);
+  // Above 128 chains the 8-wave workgroup wins: every tile is fetched from L2 by half as many workgroups
+  // (measured at 1024 chains: 6.5 ms against 7.1 ms).  Up to 128 chains 4-wave workgroups, two per CU; up to 64
+  // chains with one 16-chain tile per wave, which halves the matrix work per tile and leaves the kernel close
+  // to the memory system's pace (N = 10M, D = 64, 64 chains: 0.73 ms against 1.05 ms).
+  const bool wide = plane_cols(d) == 64;
+  if (c <= 64)
+    return wide ? launch_f16<64, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s)
+                : launch_f16<32, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s);
+  if (c <= 128)
+    return wide ? launch_f16<64, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s)
+                : launch_f16<32, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s);
+  return wide ? launch_f16<64, 8, 2>(pk, n, d, theta, c, logp, grad, ws, s)
+              : launch_f16<32, 8, 2>(pk, n, d, theta, c, logp, grad, ws, s);
 }

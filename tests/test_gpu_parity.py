@@ -153,10 +153,12 @@ def _f16_eval(nat, ws, gpu_device, X, y, th):
 @pytest.mark.parametrize('d,c,n', [(64, 1, 1), (64, 128, 64), (64, 256, 1000), (64, 300, 4096 + 17), (32, 128, 5000),
                                    (64, 1024, 20000), (32, 513, 777), (64, 32, 300), (64, 130, 200000),
                                    (32, 3, 63), (64, 257, 65), (1, 130, 3000), (5, 128, 20000), (17, 200, 4097),
-                                   (33, 129, 1000), (48, 256, 30000), (63, 64, 500)])
+                                   (33, 129, 1000), (48, 256, 30000), (63, 64, 500), (64, 17, 3000), (64, 64, 20000),
+                                   (32, 40, 5000), (17, 33, 4097), (64, 65, 2000)])
 def test_linreg_f16_pieces(nat, ws, gpu_device, d, c, n):
-    """The f16-piece kernel (X in 2 pieces, W in 3, residuals in 2; power-of-two range scaling)
-    must meet the same 1e-5 bar as the exact-f32 kernels."""
+    """The f16-piece kernel (X, W and the residuals in 2 pieces each, the remainder of W compensated in closed
+    form; power-of-two range scaling) must meet the same 1e-5 bar as the exact-f32 kernels.  At most 64 chains
+    run one 16-chain tile per wave, up to 128 two tiles in 4-wave workgroups, more in 8-wave workgroups."""
     rng = np.random.default_rng(7 * d + c + n)
     X, y, th = _linreg_case(rng, n, d, c, spread=0.05 if n < 100000 else 0.005)
     ref_lp, ref_g = cf.linreg(X, y, th)
@@ -165,12 +167,13 @@ def test_linreg_f16_pieces(nat, ws, gpu_device, d, c, n):
     assert_grad_close(g, ref_g, term_scale=_linreg_term_scale(X, y, th))
 
 
-def test_linreg_f16_pieces_near_mode(nat, ws, gpu_device):
+@pytest.mark.parametrize('c', [128, 48])
+def test_linreg_f16_pieces_near_mode(nat, ws, gpu_device, c):
     """Chains packed tightly around the mode: the gradient is a small difference of large sums and an
-    error in W common to all rows would grow like n (the reason for the third piece of W).  The
-    error must stay within a small multiple of the exact-f32 kernel's own."""
+    error in W common to all rows would grow like n (the reason the remainder of W after two pieces is
+    compensated with X^T X).  The error must stay within a small multiple of the exact-f32 kernel's own."""
     rng = np.random.default_rng(99)
-    n, d, c = 400000, 64, 128
+    n, d = 400000, 64
     X, y, th = _linreg_case(rng, n, d, c, spread=0.001)
     ref_lp, ref_g = cf.linreg(X, y, th)
     lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
@@ -246,14 +249,14 @@ def test_linear_regression_auto_runs_f16_pieces(nat, ws, gpu_device):
     X, y, th = _linreg_case(rng, 20000, 64, 256)
     Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
     lik = LinearRegression(Xd, yd)
-    assert lik.matrix_core_format(256) == nat.PACK_F16 and lik.matrix_core_format(40) == nat.PACK_F16 \
-        and lik.matrix_core_format(32) is None
+    assert lik.matrix_core_format(256) == nat.PACK_F16 and lik.matrix_core_format(17) == nat.PACK_F16 \
+        and lik.matrix_core_format(16) is None
     lp, g = lik.logp_grad(thd)
     pk = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
     lp_p, g_p = nat.linreg_packed_logp_grad(pk, 20000, 64, thd, ws, fmt=nat.PACK_F16)
     assert torch.equal(lp, lp_p) and torch.equal(g, g_p)
-    lp_s, g_s = lik.logp_grad(thd[:32].contiguous())
-    lp_f, g_f = nat.linreg_logp_grad(Xd, yd, thd[:32].contiguous(), ws, precision=nat.PREC_F32)
+    lp_s, g_s = lik.logp_grad(thd[:16].contiguous())
+    lp_f, g_f = nat.linreg_logp_grad(Xd, yd, thd[:16].contiguous(), ws, precision=nat.PREC_F32)
     assert torch.equal(lp_s, lp_f) and torch.equal(g_s, g_f)
 
 
