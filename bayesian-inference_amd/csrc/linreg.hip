@@ -231,8 +231,11 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ X, int64_t row, i
   return v;
 }
 
+// (one chain tile per wave = the streaming regime: held to 128 registers so that four waves per SIMD keep more
+// loads in flight)
 template <int DT, int NC, bool VEC>
-__global__ __launch_bounds__(256) void linreg_f32_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NC == 1 ? 4 : 1, NC == 1 ? 4 : 8)))
+void linreg_f32_kernel(const float* __restrict__ X,
                                                          const float* __restrict__ y, int64_t n, int d,
                                                          const float* __restrict__ theta, int C, int ncg,
                                                          float* __restrict__ partials) {
