@@ -93,6 +93,17 @@ __device__ __forceinline__ float pow2_scale(float amax) {
   return ldexpf(1.f, min(max(13 - ilogbf(amax), -126), 126));
 }
 
+// First f16 piece of a scaled weight q (|q| < 2^14): the nearest multiple of kWGrid, or of the f16 spacing at q where
+// that is coarser.  A weight far below its chain's largest one thus keeps only a few bits in the first piece (the rest
+// goes to the second piece and the compensated remainder), so that its products with x' carry no bits far below the
+// ones of the large products they are summed with: the matrix instruction cuts every addend off, toward zero, a few
+// bits below the largest addend's last bit, which for full-mantissa small products is a loss with a sign.
+constexpr float kWGrid = 1.f;
+__device__ __forceinline__ _Float16 first_piece(float q) {
+  const float g = rintf(q * (1.f / kWGrid)) * kWGrid;
+  return fabsf(q) < 1024.f * kWGrid ? (_Float16)g : (_Float16)q;
+}
+
 // (q0, q1) -> packed f16 (hi0, hi1) and (lo0, lo1) with lo = f16(q - hi): one packed convert and two
 // mixed-precision fma that read the f16 halves directly
 __device__ __forceinline__ void split_pair(float q0, float q1, unsigned& hi, unsigned& lo) {
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float q = v[ks][j] * t;
-          const _Float16 hi = (_Float16)q;
+          const _Float16 hi = first_piece(q);
           const _Float16 lo = (_Float16)(q - (float)hi);
           w1[ct][ks][j] = hi;
           w2[ct][ks][j] = lo;       // what is left, (q - hi) - lo, is accounted for in the finalize kernel
@@ -555,7 +566,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     const float t = pow2_scale(amax);
     const float q = v * t;
-    const _Float16 hi = (_Float16)q;
+    const _Float16 hi = first_piece(q);
     const _Float16 lo = (_Float16)(q - (float)hi);
     const float rem = (q - (float)hi) - (float)lo;
     dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;

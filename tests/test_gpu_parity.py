@@ -3,6 +3,8 @@ closed-form oracle on the same seeded inputs and against the golden vectors."""
 import json
 import os
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -184,6 +186,33 @@ def test_linreg_f16_pieces_near_mode(nat, ws, gpu_device, c):
     e32 = (np.abs(g32.cpu().numpy() - ref_g) / scale).max()
     assert_logp_close(lp, ref_lp)
     assert e16 <= max(4.0 * e32, 1e-5), (e16, e32)
+
+
+def test_linreg_f16_pieces_at_the_mode_small_weights(nat, ws, gpu_device):
+    """Chains within one posterior standard deviation of the mode, weights spanning three decades: the
+    matrix instruction cuts small addends off toward zero, which for full-mantissa pieces of the small weights
+    was a loss with a sign (gradient error on exactly those features, the same for every chain, 10x the
+    exact-f32 kernel's).  With the first piece of W on a grid relative to the chain's largest weight the error
+    must stay within a small multiple of the exact-f32 kernel's own."""
+    rng = np.random.default_rng(17)
+    n, d, c = 300000, 64, 48
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    w = rng.normal(size=d) * 10.0 ** rng.uniform(-3, 0, d)
+    y = (0.5 + X.astype(np.float64) @ w + rng.normal(size=n)).astype(np.float32)
+    A = np.concatenate([np.ones((n, 1)), X.astype(np.float64)], 1)
+    ols = np.linalg.lstsq(A, y.astype(np.float64), rcond=None)[0]
+    width = 1.0 / math.sqrt(n)
+    th = np.concatenate([ols[None, :1] + width * rng.normal(size=(c, 1)), ols[None, 1:] + width * rng.normal(size=(c, d)),
+                         np.ones((c, 1))], -1).astype(np.float32)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
+    lp32, g32 = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws,
+                                     precision=nat.PREC_F32)
+    scale = np.abs(ref_g[:, 1:1 + d]).max(-1, keepdims=True)
+    e16 = (np.abs(g - ref_g)[:, 1:1 + d] / scale).max()
+    e32 = (np.abs(g32.cpu().numpy() - ref_g)[:, 1:1 + d] / scale).max()
+    assert_logp_close(lp, ref_lp)
+    assert e16 <= 3.0 * e32, (e16, e32)
 
 
 def test_linreg_f16_pieces_column_ranges(nat, ws, gpu_device):

@@ -2,7 +2,9 @@
 posterior standard deviation): per chain / per feature, against the exact-f32 kernel, and regressed on candidate
 directions.  Finding: the error is the same for every chain, sits on the features with the smallest weights and has
 the sign of that weight -- sign(w_d) * const * sum_i |x_id| -- which is what cutting off small addends toward zero
-inside the matrix instruction produces (see mfma_rounding.hip)."""
+inside the matrix instruction produces (see mfma_rounding.hip).  That was with a floating hi / lo split of W; with the
+first piece on a grid relative to the chain's largest weight (first_piece in linreg_f16.hip) the feature-specific part
+is gone."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
