@@ -61,16 +61,22 @@ class ShardedLogLikelihood:
         grad = buf[c:].view(c, self.n_params) if want_grad else None
         self._call(theta, logp, grad)
         if self.sharded:
+            # a gloo group cannot reduce device memory (it waits for ever): such a group -- a rehearsal of the
+            # multi-rank path on fewer GPUs than ranks -- gets the buffer staged through the host
+            staged = buf.is_cuda and dist.get_backend(self.group) == 'gloo'
+            wire = buf.cpu() if staged else buf
             if self.fixed_order_reduction:
                 world = dist.get_world_size(self.group)
-                parts = torch.empty(world * buf.numel(), dtype=buf.dtype, device=buf.device)
-                dist.all_gather_into_tensor(parts, buf, group=self.group)
-                total = parts[:buf.numel()].clone()
+                parts = torch.empty(world * wire.numel(), dtype=wire.dtype, device=wire.device)
+                dist.all_gather_into_tensor(parts, wire, group=self.group)
+                total = parts[:wire.numel()].clone()
                 for r in range(1, world):           # rank order, the same on every rank
-                    total += parts[r * buf.numel():(r + 1) * buf.numel()]
+                    total += parts[r * wire.numel():(r + 1) * wire.numel()]
                 buf.copy_(total)
             else:
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+                if staged:
+                    buf.copy_(wire)
         return logp, grad
 
 
