@@ -80,6 +80,22 @@ class ShardedLogLikelihood:
         return logp, grad
 
 
+def replicate_from_rank0(tensor, group):
+    """Every rank of a row-sharded run must hold the same chains / surrogate parameters / random stream; this makes
+    `tensor` on all ranks equal to rank 0's, in place (a gloo group gets device memory staged through the host)."""
+    if group is None or not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return tensor
+    src = dist.get_global_rank(group, 0) if hasattr(dist, 'get_global_rank') else 0
+    if tensor.is_cuda and dist.get_backend(group) == 'gloo':
+        wire = tensor.detach().cpu()
+        dist.broadcast(wire, src=src, group=group)
+        with torch.no_grad():
+            tensor.copy_(wire)
+    else:
+        dist.broadcast(tensor.detach(), src=src, group=group)
+    return tensor
+
+
 class FusedLogLikelihood(ShardedLogLikelihood):
     """The local partial sums come from one fused HIP pass through the C ABI.  MI355X only."""
 

@@ -3,6 +3,7 @@ import collections
 
 import torch
 
+from ...fused_target import replicate_from_rank0
 from ..inference import Inference
 from .sample_results import SampleResult
 from .samplers import sample_chain
@@ -28,6 +29,7 @@ class MCMC(Inference):
                                                                precision=precision)
         self.posterior = self.distribution.posterior(self.targets)
         self.device = self.posterior.likelihood.device
+        self.group = group
         self.transition_kernel = transition_kernel if transition_kernel is not None else RandomWalkMetropolis()
 
     def target_log_prob(self, state):
@@ -56,6 +58,9 @@ class MCMC(Inference):
         if seed is not None:
             gen = torch.Generator(device='cpu'); gen.manual_seed(int(seed))
         z0 = self._process_initial_state(initial_state, num_chains, generator=gen)
+        # rows sharded over ranks: the chains are replicated, so all ranks start where rank 0 starts (pass `seed`
+        # as well when a kernel draws from torch's generators rather than from the counter-based device streams)
+        z0 = replicate_from_rank0(z0.contiguous(), self.group)
         dgen = None
         if seed is not None:
             dgen = torch.Generator(device=self.device); dgen.manual_seed(int(seed) + 1)

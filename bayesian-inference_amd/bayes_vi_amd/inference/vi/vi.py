@@ -2,7 +2,7 @@
 import numpy as np
 import torch
 
-from ...fused_target import differentiable_log_prob
+from ...fused_target import differentiable_log_prob, replicate_from_rank0
 from ..inference import Inference
 
 
@@ -39,6 +39,15 @@ class VI(Inference):
         self.posterior = self.distribution.posterior(self.targets)
         self.device = self.posterior.likelihood.device
         self.surrogate_posterior = surrogate_posterior.to(self.device)
+        self.group = group
+        # rows sharded over ranks: every rank optimises the same surrogate on the same Monte-Carlo samples, so the
+        # parameters and the device's random stream are taken from rank 0
+        for p in self.surrogate_posterior.parameters():
+            replicate_from_rank0(p.data, group)
+        if getattr(self.posterior.likelihood, 'sharded', False) or \
+                getattr(getattr(self.posterior.likelihood, 'inner', None), 'sharded', False):
+            seed = replicate_from_rank0(torch.tensor([torch.initial_seed() % (1 << 62)], dtype=torch.int64), group)
+            torch.manual_seed(int(seed[0]))
         p = self.model.flat_param_event_ndims
         base = lambda sample: differentiable_log_prob(self.posterior, sample[:, :p].contiguous())
         self.target_log_prob = self.surrogate_posterior.get_corrected_target_log_prob_fn(base)

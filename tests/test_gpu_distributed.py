@@ -60,7 +60,30 @@ def _worker(rank, world, port, out_dir):
     shard = TensorDataset(X, y).shard(rank, world)
     post = _posterior(shard.features, shard.targets, dist.group.WORLD)
     assert post.likelihood.sharded
-    torch.save(_run(post, z), os.path.join(out_dir, 'rank%d.pt' % rank))
+    res = _run(post, z)
+    # the public drivers: ranks that seeded their own generators differently still run the same chains / the same
+    # surrogate, because initial states, surrogate parameters and the device's random stream come from rank 0
+    import collections
+    from bayes_vi_amd import distributions as tfd, symbolic
+    from bayes_vi_amd.model import Model
+    from bayes_vi_amd.inference.mcmc import MCMC
+    from bayes_vi_amd.inference.mcmc.transition_kernels import HamiltonianMonteCarlo
+    from bayes_vi_amd.inference.vi import VI
+    from bayes_vi_amd.inference.vi.vi import Adam
+    from bayes_vi_amd.inference.vi.surrogate_posteriors import ADVI
+    priors = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros(D), 10.),
+                                     scale=tfd.HalfNormal(10.))
+    model = Model(priors, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
+    ds = TensorDataset(shard.features.cuda(), shard.targets.cuda())
+    torch.manual_seed(100 + rank)
+    mc = MCMC(model, ds, HamiltonianMonteCarlo(step_size=1e-3, num_leapfrog_steps=3), group=dist.group.WORLD)
+    out = mc.fit(num_chains=3, num_samples=4, num_burnin_steps=2, progress_bar=False)
+    res['mcmc_w'] = out.samples[1].cpu()
+    torch.manual_seed(200 + rank)
+    vi = VI(model, ds, ADVI(model, mean_field=True), group=dist.group.WORLD)
+    _, losses = vi.fit(Adam(1e-2), num_steps=6, sample_size=8, num_samples_to_approx_marginals=10, progress_bar=False)
+    res['vi_losses'] = torch.tensor(losses)
+    torch.save(res, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,10 +104,14 @@ def test_two_ranks_on_one_gpu_stay_replicated_and_match_the_unsharded_run(gpu_de
     assert not hung, 'a rank did not finish'
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     r0, r1 = (torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in range(2))
+    assert set(r0) == set(r1)
     for k in r0:
-        assert torch.equal(r0[k], r1[k]), k           # replicated chains: same bits on every rank
+        assert torch.equal(r0[k], r1[k]), k           # replicated chains / surrogate: same bits on every rank
+    assert bool(torch.isfinite(r0['vi_losses']).all()) and r0['mcmc_w'].shape == (4, 3, D)
     X, y, z = _make()
     ref = _run(_posterior(X, y, None), z)
+    for k in ('mcmc_w', 'vi_losses'):
+        r0.pop(k)
     np.testing.assert_allclose(r0['lp'].numpy(), ref['lp'].numpy(), rtol=2e-6)
     gs = np.abs(ref['g'].numpy()).max()
     np.testing.assert_allclose(r0['g'].numpy(), ref['g'].numpy(), rtol=1e-4, atol=1e-5 * gs)
