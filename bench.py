@@ -223,7 +223,7 @@ def main():
         'dtype': {None: 'f32', _native.PACK_F16: 'f32 (f16 2-piece split MFMA + closed-form compensation, f32 accumulate)',
                   _native.PACK_BF16X3: 'f32 (bf16 3-piece split MFMA, f32 accumulate)'}[fmt],
         'data': 'synthetic',
-        'config': {'workload': 'Bayesian linear regression, HMC leapfrog gradient evaluations (BASELINE configs[1])',
+        'config': {'workload': 'Bayesian linear regression, HMC leapfrog gradient evaluations (BASELINE.json configs[1])',
                    'rows': n, 'rows_per_gpu': n_local, 'features': d, 'chains': c, 'precision': args.precision,
                    'parallelism': 'rows sharded over %d GPU(s), chains replicated, all-reduce of [C,1+P] per step' % world},
         'roofline': {

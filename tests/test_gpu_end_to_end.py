@@ -112,7 +112,7 @@ def test_posterior_assembly_matches_oracle_all_families(bvi, gpu_device):
 
 
 def test_config1_nuts_dual_averaging(bvi):
-    """BASELINE configs[0]: univariate Gaussian, 20 points, NUTS + DualAveraging, 2 chains
+    """BASELINE.json configs[0]: univariate Gaussian, 20 points, NUTS + DualAveraging, 2 chains
     (README.md:146-162; draws reduced to keep the test short).  Moments within Monte-Carlo error of
     the exact posterior moments (quadrature of the oracle's log posterior)."""
     rng = np.random.default_rng(1)
@@ -384,7 +384,7 @@ def test_fused_hmc_kernel_matches_oracle_and_unfused_device_path(bvi, gpu_device
 
 
 def test_fused_hmc_through_mcmc_fit_posterior_moments(bvi):
-    """BASELINE configs[0] data (20 points) through MCMC.fit with HMC: the driver picks the fused
+    """BASELINE.json configs[0] data (20 points) through MCMC.fit with HMC: the driver picks the fused
     kernel, adapts the step size transition by transition, then draws every sample in one launch.
     Posterior moments within Monte-Carlo error of the exact ones."""
     from bayes_vi_amd.inference.mcmc.device_hmc import FusedHamiltonianMonteCarloKernel
@@ -630,7 +630,7 @@ def test_batched_device_nuts_through_mcmc_fit_on_a_large_regression(bvi, gpu_dev
 
 
 def test_fused_nuts_through_mcmc_fit(bvi):
-    """BASELINE configs[0] through MCMC.fit: the driver selects the fused NUTS kernel; dual averaging runs
+    """BASELINE.json configs[0] through MCMC.fit: the driver selects the fused NUTS kernel; dual averaging runs
     transition by transition during adaptation, the remaining burn-in and all samples are one launch each."""
     from bayes_vi_amd.inference.mcmc.device_hmc import FusedNoUTurnSamplerKernel
     rng = np.random.default_rng(1)
@@ -653,7 +653,7 @@ def test_fused_nuts_through_mcmc_fit(bvi):
 
 
 def test_fullcov_mixture_posterior_and_nuts(bvi, gpu_device):
-    """BASELINE configs[3] in miniature: full-covariance mixture, FillScaleTriL-constrained Cholesky
+    """BASELINE.json configs[3] in miniature: full-covariance mixture, FillScaleTriL-constrained Cholesky
     factors, posterior assembly against the oracle and a short NUTS run."""
     import bayes_vi_amd.bijectors as tfb
     rng = np.random.default_rng(6)

@@ -70,7 +70,7 @@ def _reference_from_stats(r, th):
 
 
 def test_regression_10m_rows_1024_chains_against_float64_statistics(nat, ws, regression_10m):
-    """BASELINE configs[1] in full: the f16-piece matrix-core kernel on 10M x 64 with 1024 chains
+    """BASELINE.json configs[1] in full: the f16-piece matrix-core kernel on 10M x 64 with 1024 chains
     against the float64 sufficient-statistics evaluation; the exact-f32 kernel on 64 of the chains."""
     r = regression_10m
     n, d, th = r['n'], r['d'], r['th']
@@ -134,7 +134,7 @@ def test_regression_10m_rescaling_property(nat, ws, regression_10m):
 
 
 def test_mixture_100m_rows(nat, ws, gpu_device):
-    """BASELINE configs[2] size: K = 8 mixture over 100M rows.  Row shards (cut at an odd row, so the
+    """BASELINE.json configs[2] size: K = 8 mixture over 100M rows.  Row shards (cut at an odd row, so the
     second shard is not 16-byte aligned) add up; two chains against a chunked float64 evaluation."""
     n, k, c = 100_000_000, 8, 16
     g = torch.Generator(device=gpu_device); g.manual_seed(7)
@@ -198,7 +198,7 @@ def test_normal_100m_rows(nat, ws, gpu_device):
 
 
 def test_fullcov_mixture_1m_rows_shards_add(nat, ws, gpu_device):
-    """BASELINE configs[3] shape (D = 32, K = 16, full covariance): shard additivity at 1M rows."""
+    """BASELINE.json configs[3] shape (D = 32, K = 16, full covariance): shard additivity at 1M rows."""
     n, d, k, c = 1_000_000, 32, 16, 4
     g = torch.Generator(device=gpu_device); g.manual_seed(11)
     centers = 4 * torch.randn(k, d, generator=g, device=gpu_device)

@@ -1,4 +1,4 @@
-"""BASELINE configs[0]: univariate Gaussian, 20 points, NUTS + dual averaging, 2 chains x 4000 samples
+"""BASELINE.json configs[0]: univariate Gaussian, 20 points, NUTS + dual averaging, 2 chains x 4000 samples
 (README.md:146-162): wall time of MCMC.fit, and of HMC on the same posterior."""
 import collections, os, sys, time
 import numpy as np, pandas as pd, torch

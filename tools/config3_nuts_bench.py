@@ -1,4 +1,4 @@
-"""BASELINE configs[3] shape (full-covariance mixture, D = 32, K = 16, NUTS): time per lock-step leapfrog
+"""BASELINE.json configs[3] shape (full-covariance mixture, D = 32, K = 16, NUTS): time per lock-step leapfrog
 of (a) host tree bookkeeping + posterior assembly in torch ops, (b) host bookkeeping + device assembly,
 (c) device bookkeeping + device assembly.  Usage: config3_nuts_bench.py [N] [C]  (N = rows on this GPU)."""
 import collections, os, sys, time

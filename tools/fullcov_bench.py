@@ -1,4 +1,4 @@
-"""Times the full-covariance mixture entry point at the BASELINE configs[3] shape (N, C chosen here)."""
+"""Times the full-covariance mixture entry point at the BASELINE.json configs[3] shape (N, C chosen here)."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""HMC transitions per second on the 20-point Gaussian of BASELINE configs[0]: whole run in one launch
+"""HMC transitions per second on the 20-point Gaussian of BASELINE.json configs[0]: whole run in one launch
 (bvi_hmc_fused) against the launch-per-leapfrog-step device path."""
 import collections, os, sys, time
 import numpy as np, pandas as pd, torch

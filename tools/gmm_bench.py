@@ -1,4 +1,4 @@
-"""Kernel time of the 1-D mixture and iid-Normal likelihoods at BASELINE configs[2] size (N = 100M, K = 8)."""
+"""Kernel time of the 1-D mixture and iid-Normal likelihoods at BASELINE.json configs[2] size (N = 100M, K = 8)."""
 import os, sys, argparse
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,4 @@
-"""BASELINE configs[4] on one GPU: ELBO gradient steps of mean-field ADVI (and a Hamiltonian-flow surrogate)
+"""BASELINE.json configs[4] on one GPU: ELBO gradient steps of mean-field ADVI (and a Hamiltonian-flow surrogate)
 on the 10M x 64 regression with 256 Monte-Carlo samples per step."""
 import collections, os, sys, time
 import numpy as np, pandas as pd, torch
