@@ -390,6 +390,7 @@ class BatchedDeviceNoUTurnSamplerKernel:
                                  if n not in ('z', 'lp', 'grad')})
         flag, nflag = b['any'], 0
         flag.zero_()
+        flag_ptr = flag.data_ptr()          # word n of `flag` is passed as an address: no tensor view per launch
         _native.check(lib.bvi_nuts_begin(s, seed, step, st), 'bvi_nuts_begin')
         lik = self.posterior.likelihood
         for depth in range(self.max_tree_depth):
@@ -404,14 +405,14 @@ class BatchedDeviceNoUTurnSamplerKernel:
                                                               ptr(b['p']), ptr(b['theta']), ptr(ll), ptr(gl),
                                                               ptr(b['lpq']), ptr(b['gq']), st),
                               'bvi_leapfrog_post_chainwise')
-                _native.check(lib.bvi_nuts_leaf(s, seed, step, leaf, ptr(flag[nflag:]), st), 'bvi_nuts_leaf')
+                _native.check(lib.bvi_nuts_leaf(s, seed, step, leaf, flag_ptr + 4 * nflag, st), 'bvi_nuts_leaf')
                 nflag += 1
                 # The host only needs to know when NO chain is building any more.  U-turns inside a subtree
                 # are found at odd leaves, so that is when the word is read back (a divergence at an even
                 # leaf is noticed one frozen leapfrog late); after the last leaf the subtree ends either way.
                 if (leaf & 1) and leaf + 1 < n_leaves and int(flag[nflag - 1].item()) == 0:
                     break
-            _native.check(lib.bvi_nuts_subtree_end(s, ptr(flag[nflag:]), st), 'bvi_nuts_subtree_end')
+            _native.check(lib.bvi_nuts_subtree_end(s, flag_ptr + 4 * nflag, st), 'bvi_nuts_subtree_end')
             nflag += 1
             if depth + 1 < self.max_tree_depth and int(flag[nflag - 1].item()) == 0:
                 break
