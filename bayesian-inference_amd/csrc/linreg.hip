@@ -393,18 +393,10 @@ void linreg_f32_kernel(const float* __restrict__ X,
 
 // ---------------------------------------------------------------------------
 // finalize: fixed-order reduction over row blocks (double) + scaling.
-// One thread, or for many row blocks one wave, per (chain, raw-sum index).
 // ---------------------------------------------------------------------------
-template <bool WAVE>
-__global__ void linreg_finalize(const float* __restrict__ partials, int nb, int64_t n, int d,
-                                const float* __restrict__ theta, int C, float* __restrict__ logp,
-                                float* __restrict__ grad) {
+__device__ __forceinline__ void linreg_finish(double s, int c, int q, int64_t n, int d, const float* __restrict__ theta,
+                                              float* __restrict__ logp, float* __restrict__ grad) {
   const int q2 = d + 2;
-  const int idx = WAVE ? (blockIdx.x * blockDim.x + threadIdx.x) >> 6 : blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= C * q2) return;
-  const int c = idx / q2, q = idx - c * q2;
-  const double s = bvi_sum_partials<WAVE>(partials + (int64_t)c * q2 + q, nb, (int64_t)C * q2);
-  if (WAVE && (threadIdx.x & 63) != 0) return;
   const double sc = (double)theta[(int64_t)c * q2 + d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   if (q == 0) {
@@ -415,13 +407,46 @@ __global__ void linreg_finalize(const float* __restrict__ partials, int nb, int6
   }
 }
 
+// few row blocks: one thread per (chain, raw-sum index)
+__global__ void linreg_finalize(const float* __restrict__ partials, int nb, int64_t n, int d,
+                                const float* __restrict__ theta, int C, float* __restrict__ logp,
+                                float* __restrict__ grad) {
+  const int q2 = d + 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * q2) return;
+  const int c = idx / q2, q = idx - c * q2;
+  const double s = bvi_sum_partials<false>(partials + (int64_t)c * q2 + q, nb, (int64_t)C * q2);
+  linreg_finish(s, c, q, n, d, theta, logp, grad);
+}
+
+// many row blocks: a workgroup owns 64 consecutive outputs (consecutive lanes read consecutive sums of a row
+// block); its 16 waves take every 16th row block and are combined in wave order through LDS
+__global__ __launch_bounds__(1024) void linreg_finalize_tiled(const float* __restrict__ partials, int nb, int64_t n,
+                                                              int d, const float* __restrict__ theta, int C,
+                                                              float* __restrict__ logp, float* __restrict__ grad) {
+  const int q2 = d + 2, tot = C * q2;
+  const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
+  __shared__ double part[16][64];
+  double s = 0.0;
+  if (idx < tot) {
+#pragma unroll 4
+    for (int b = grp; b < nb; b += 16) s += (double)partials[(int64_t)b * tot + idx];
+  }
+  part[grp][o] = s;
+  __syncthreads();
+  if (grp != 0 || idx >= tot) return;
+  for (int w = 1; w < 16; ++w) s += part[w][o];
+  linreg_finish(s, idx / q2, idx % q2, n, d, theta, logp, grad);
+}
+
 static void launch_linreg_finalize(int tot, hipStream_t s, const float* ws, int nb, int64_t n, int d,
                                    const float* theta, int c, float* logp, float* grad) {
   if (nb > 32)
-    hipLaunchKernelGGL(linreg_finalize<true>, dim3(bvi_ceil_div(tot, 4)), dim3(256), 0, s, ws, nb, n, d, theta, c,
+    hipLaunchKernelGGL(linreg_finalize_tiled, dim3(bvi_ceil_div(tot, 64)), dim3(1024), 0, s, ws, nb, n, d, theta, c,
                        logp, grad);
   else
-    hipLaunchKernelGGL(linreg_finalize<false>, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, ws, nb, n, d, theta, c,
+    hipLaunchKernelGGL(linreg_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, ws, nb, n, d, theta, c,
                        logp, grad);
 }
 
