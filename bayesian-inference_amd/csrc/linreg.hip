@@ -430,7 +430,7 @@ __global__ __launch_bounds__(1024) void linreg_finalize_tiled(const float* __res
   __shared__ double part[16][64];
   double s = 0.0;
   if (idx < tot) {
-#pragma unroll 4
+#pragma unroll 16
     for (int b = grp; b < nb; b += 16) s += (double)partials[(int64_t)b * tot + idx];
   }
   part[grp][o] = s;

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     const int q = q0 + o;
     double s = 0.0;
     if (q < q2 && q != 1) {
-#pragma unroll 4
+#pragma unroll 16
       for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + (int64_t)c * q2 + q];
     }
     part[grp][o] = s;
