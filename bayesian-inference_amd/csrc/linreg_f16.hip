@@ -539,11 +539,12 @@ __global__ void f16_gram_final(const double* __restrict__ gpart, int nblk, int D
   gram[e] = s;
 }
 
-// finalize, one workgroup of 16 waves per chain: fixed-order reduction over row blocks in double (a wave takes
-// every 16th row block; consecutive lanes read consecutive sums), undoing the power-of-two scales, the closed-form
-// correction for the part of W that its two f16 pieces do not hold (see the top of this file), S1 from the packed
-// data sums.
-constexpr int kFinGroups = 16;
+// finalize, one workgroup of kFinGroups waves per chain: fixed-order reduction over row blocks in double (a wave
+// takes every kFinGroups-th row block; consecutive lanes read consecutive sums), undoing the power-of-two scales, the
+// closed-form correction for the part of W that its two f16 pieces do not hold (see the top of this file), S1 from
+// the packed data sums.  16 waves when there are few chains (the chip is filled by waves per chain), 4 when there
+// are many (all workgroups resident at once).
+template <int kFinGroups>
 __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     const float* __restrict__ partials, const float* __restrict__ ublk, int cpb, int nb, int64_t n, int d,
     const unsigned char* __restrict__ packed, const float* __restrict__ theta, int C, float* __restrict__ logp,
@@ -589,12 +590,19 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const double u = (double)ublk[c / cpb];
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
+  {
+    double cf = 0.0;                                                             // (X^T X dw)_f, X^T X symmetric:
+    if (o < d)                                                                   // a wave takes every kFinGroups-th g
+      for (int g = grp; g < d; g += kFinGroups) cf = fma(gram[g * 64 + o], dw[g], cf);
+    part[grp][o] = cf;
+  }
+  __syncthreads();
   if (threadIdx.x < d) {
     const int f = threadIdx.x;
     const double cs = (double)hdr->colscale[f];
     const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;   // G'_f = u s_f G_f
-    double cf = 0.0;
-    for (int g = 0; g < d; ++g) cf = fma(gram[g * 64 + f], dw[g], cf);          // (X^T X dw)_f, X^T X symmetric
+    double cf = part[0][f];
+    for (int w = 1; w < kFinGroups; ++w) cf += part[w][f];
     gc[f] = g0;
     corr[f] = cf;
     if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - cf) * inv2);
@@ -678,18 +686,26 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   // workspace: partials [nrb][c][d+2], then one residual scale per chain block
   float* ublk = ws + (size_t)nrb * c * (d + 2);
   const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * D + 2 * kTileRows * 4);
-  static bool lds_ok = false;                 // > 64 KB of dynamic LDS has to be allowed once per kernel
-  if (!lds_ok) {
+  // > 64 KB of dynamic LDS has to be allowed once per kernel and device (setting it twice from two threads is
+  // harmless)
+  static bool lds_ok[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return BVI_ERR_ARG;
+  if (!lds_ok[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW, CT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_ok = true;
+    lds_ok[dev] = true;
   }
   hipLaunchKernelGGL((linreg_f16_kernel<D, NW, CT>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb,
                      ws, ublk);
   BVI_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(linreg_f16_finalize, dim3(c), dim3(64 * kFinGroups), 0, s, (const float*)ws,
-                     (const float*)ublk, cpb, nrb, n, d, pk, theta, c, logp, grad);
+  if (c > 256)
+    hipLaunchKernelGGL(linreg_f16_finalize<4>, dim3(c), dim3(256), 0, s, (const float*)ws, (const float*)ublk, cpb,
+                       nrb, n, d, pk, theta, c, logp, grad);
+  else
+    hipLaunchKernelGGL(linreg_f16_finalize<16>, dim3(c), dim3(1024), 0, s, (const float*)ws, (const float*)ublk, cpb,
+                       nrb, n, d, pk, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
