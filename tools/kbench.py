@@ -14,7 +14,10 @@ ap.add_argument('--prec', default='bf16x6')
 ap.add_argument('--check', action='store_true')
 ap.add_argument('--packed', action='store_true')
 ap.add_argument('--f16', action='store_true')
+ap.add_argument('--lib', default=None, help='alternative build of the library (kernel experiments)')
 a = ap.parse_args()
+if a.lib:
+    nat._LIB_PATH = os.path.abspath(a.lib)
 dev = torch.device('cuda:0'); ws = nat.Workspace(dev)
 g = torch.Generator(device=dev); g.manual_seed(1)
 X = torch.empty(a.rows, a.d, device=dev)
