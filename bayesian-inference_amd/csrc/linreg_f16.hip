@@ -51,6 +51,10 @@
 // The loop is bound by vector-instruction issue (an MFMA of this shape holds the issue port for 8
 // of its 16 cycles), so everything per residual that is not an MFMA is kept to: two fma (assemble
 // r'), one fma (S2'), one packed convert and one mixed-precision fma (hi / lo split).
+// The chip also lowers its clock under this load (1.9 - 1.95 GHz sustained, tools/clock_probe.sh), and more so
+// under a denser one: the same pass on v_mfma_f32_32x32x16_f16 (half the matrix instructions, 32 chains per wave,
+// the accumulator registers 8 s .. 8 s + 7 as the A operand of the second product's k-step s) took the same number
+// of cycles but ran at 1.71 - 1.75 GHz, 6.4 ms against 5.8 ms, and was dropped.
 #include <stdlib.h>
 #include "bvi_common.h"
 
@@ -373,252 +377,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int i = 0; i < 4; ++i) {
         const int c = cbase + 16 * ct + 4 * g + i;
         if (c < C && 16 * ft + ln < dr) partials[((int64_t)rbi * C + c) * (dr + 2) + 2 + 16 * ft + ln] = G[ct][ft][i];
-      }
-  }
-}
-
-// The same pass on v_mfma_f32_32x32x16_f16 for D = 64 and 32 chains per wave: half as many matrix instructions for
-// the same products (each holds the issue port for 8 of its 32 cycles instead of 8 of 16), everything else as above.
-// A[m][k]: lane l holds m = l & 31, k = 8 (l >> 5) .. + 7; B[k][n]: n = l & 31, same k; D[m][n]: lane l, register v
-// holds m = 8 (v >> 2) + 4 (l >> 5) + (v & 3), n = l & 31.  GEMM1: M = 32 rows, N = 32 chains, four 16-feature
-// k-steps; registers 8 s .. 8 s + 7 of its accumulator are, lane for lane, the A operand of GEMM2's k-step s
-// (M = chains, K = 16 rows, N = 32 features) with k index j <-> row 16 s + 8 (j >> 2) + 4 h + (j & 3).
-// LDS image: 128-byte rows, 16-byte chunk q of row r at chunk q ^ swz(r), swz(r) = (bit 1 of r) << 2 | bits 3:2
-// of r: the A-operand ds_read_b128 (16-lane groups = 16 rows that differ mod 16, one chunk) and the transposed
-// reads (32 lanes = 4 rows x 64 B) both spread over all 64 banks.
-typedef float f32x16v __attribute__((ext_vector_type(16)));
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16w_kernel(
-    const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
-    int nrb, float* __restrict__ partials, float* __restrict__ ublk) {
-  constexpr int D = 64;
-  constexpr int KS = 4;        // 16-feature k-steps of GEMM1
-  constexpr int FT = 2;        // 32-feature tiles of GEMM2
-  constexpr int SA = 2 * D;
-  constexpr int IMG = kTileRows * SA;
-  constexpr int BUF = 2 * IMG + 2 * kTileRows * 4;   // two planes, u*y, u*valid
-  constexpr int TPR = D / 8;
-  constexpr int NT = 64 * NW;
-  constexpr int NCH = kTileRows * TPR;
-  constexpr int PER = NCH / NT;
-  constexpr int YT = NT / kTileRows;
-  static_assert(NCH % NT == 0 && NT % kTileRows == 0, "staging shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  __shared__ float sh_u[NW];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cn = lane & 31, h = lane >> 5;
-  const int x8 = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
-  const int cbase = cbi * (32 * NW) + 32 * wave;
-  const Header* hdr = reinterpret_cast<const Header*>(packed);
-  const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
-  const int64_t n_pad = ntiles * kTileRows;
-  const unsigned char* planes = packed + kHeader;
-  const unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
-
-  f16x8 w1[KS], w2[KS];
-  float nb0, c1, u;
-  {
-    const int chain = cbase + cn;
-    const bool cvalid = chain < C;
-    const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
-    float v[KS][8], amax = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int f = 16 * ks + 8 * h + j;
-        v[ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
-        amax = fmaxf(amax, fabsf(v[ks][j]));
-      }
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));   // the two lane halves hold the chain's D features
-    const float t = pow2_scale(amax);
-    c1 = 1.f / t;
-    nb0 = cvalid ? -th[0] : 0.f;
-    float umin = resid_scale(amax, cvalid ? th[0] : 0.f, hdr->ymax, D);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float q = v[ks][j] * t;
-        const _Float16 hi = first_piece(q);
-        const _Float16 lo = (_Float16)(q - (float)hi);
-        w1[ks][j] = hi;
-        w2[ks][j] = lo;       // what is left, (q - hi) - lo, is accounted for in the finalize kernel
-      }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
-    if (lane == 0) sh_u[wave] = umin;
-    __syncthreads();
-    u = sh_u[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) u = fminf(u, sh_u[w]);
-    c1 *= u;
-    if (rbi == 0 && tid == 0) ublk[cbi] = u;
-  }
-
-  f32x16v G[FT];
-#pragma unroll
-  for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) G[ft][i] = 0.f;
-  float s2 = 0.f;
-
-  auto swz = [](int row) { return ((row & 2) << 1) | ((row >> 2) & 3); };
-  // lane-constant byte offsets inside a 32-row block of one plane: A-operand chunks per k-step, and the two 4-row
-  // blocks (rows 4 h + q and 8 + 4 h + q of a 16-row k-step) of the transposed reads per feature tile
-  int aoff[KS], xoff[FT][2];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) aoff[ks] = cn * SA + (((2 * ks + h) ^ swz(cn)) << 4);
-  {
-    const int gi = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-    const int hh = gi >> 1, nh = gi & 1;
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const int row = 8 * blk + 4 * hh + q;
-        xoff[ft][blk] = row * SA + (((4 * ft + 2 * nh + (p >> 1)) ^ swz(row)) << 4) + 8 * (p & 1);
-      }
-  }
-
-  s16x8 xp[2][PER];
-  float yp, mp;
-  auto gload = [&](int64_t tile) {
-    const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int idx = tid + e * NT;
-      const int srow = idx / TPR, ch = idx % TPR;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        xp[i][e] = *reinterpret_cast<const s16x8*>(planes + (((int64_t)i * n_pad + row0 + srow) * D + ch * 8) * 2);
-    }
-    yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
-    mp = row0 + tid / YT < n ? u : 0.f;     // padding rows: x = 0, y = 0, and no -b0 either -> r' = 0
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* base = lds + buf * BUF;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int idx = tid + e * NT;
-      const int srow = idx / TPR, ch = idx % TPR;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<s16x8*>(base + i * IMG + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[i][e];
-    }
-    *reinterpret_cast<float*>(base + 2 * IMG + (tid / YT) * 4) = yp * u;
-    *reinterpret_cast<float*>(base + 2 * IMG + kTileRows * 4 + (tid / YT) * 4) = mp;
-  };
-
-  int64_t tile = rbi;
-  if (tile < ntiles) {
-    gload(tile);
-    lstore(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (; tile < ntiles; tile += nrb) {
-    gload(tile + nrb);   // past the end: re-reads tile 0, never used
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* base = lds + buf * BUF;
-    float a2 = 0.f;             // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
-    // the A fragments of a whole 32-row block are fetched while the block before it is in its second product
-    f16x8 ah[KS], al[KS];
-    auto load_a = [&](int rb) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        ah[ks] = *reinterpret_cast<const f16x8*>(base + 32 * rb * SA + aoff[ks]);
-        al[ks] = *reinterpret_cast<const f16x8*>(base + 32 * rb * SA + IMG + aoff[ks]);
-      }
-    };
-    load_a(0);
-#pragma unroll
-    for (int rb = 0; rb < kTileRows / 32; ++rb) {
-      const unsigned char* blk = base + 32 * rb * SA;
-      f16x8 xh[3], xl[3];
-      auto load_x = [&](int s, int ft, int slot) {
-        const unsigned char* b0 = blk + 16 * s * SA + xoff[ft][0];
-        const unsigned char* b1 = blk + 16 * s * SA + xoff[ft][1];
-        const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b0);
-        const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b1);
-        const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + IMG));
-        const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b1 + IMG));
-        xh[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-        xl[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
-      };
-      // GEMM1, then r' = z' (u / t) + (u y - u b0): scaled residuals of 32 rows x this wave's 32 chains
-      f32x4v yv[4], mv[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        yv[b] = *reinterpret_cast<const f32x4v*>(base + 2 * IMG + (32 * rb + 8 * b + 4 * h) * 4);
-        mv[b] = *reinterpret_cast<const f32x4v*>(base + 2 * IMG + kTileRows * 4 + (32 * rb + 8 * b + 4 * h) * 4);
-      }
-      load_x(0, 0, 0);
-      load_x(0, 1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16v z;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], w1[ks], z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], w1[ks], z, 0, 0, 0);
-        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], w2[ks], z, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (rb + 1 < kTileRows / 32) load_a(rb + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      f16x8 rh[2], rl[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          const int v0 = 8 * s + j, v1 = v0 + 1;
-          const float q0 = fmaf(z[v0], c1, fmaf(mv[v0 >> 2][v0 & 3], nb0, yv[v0 >> 2][v0 & 3]));
-          const float q1 = fmaf(z[v1], c1, fmaf(mv[v1 >> 2][v1 & 3], nb0, yv[v1 >> 2][v1 & 3]));
-          a2 = fmaf(q0, q0, a2);
-          a2 = fmaf(q1, q1, a2);
-          split_pair(q0, q1, hw[j >> 1], lw[j >> 1]);
-        }
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        rh[s] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
-        rl[s] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
-      }
-      // GEMM2: G' += R'^T X' over the two 16-row k-steps
-#pragma unroll
-      for (int step = 0; step < 2 * FT; ++step) {
-        const int s = step / FT, ft = step % FT, cur = step % 3;     // fragments are fetched two steps ahead
-        if (step + 2 < 2 * FT) load_x((step + 2) / FT, (step + 2) % FT, (step + 2) % 3);
-        __builtin_amdgcn_sched_barrier(0);
-        G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[s], xh[cur], G[ft], 0, 0, 0);
-        G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[s], xh[cur], G[ft], 0, 0, 0);
-        G[ft] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[s], xl[cur], G[ft], 0, 0, 0);
-      }
-    }
-    s2 += a2;
-    lstore(buf ^ 1);     // as late as possible: the whole tile's arithmetic covers the HBM latency of gload
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  {
-    float v = s2 + __shfl_xor(s2, 32, 64);
-    const int chain = cbase + cn;
-    if (chain < C && h == 0) {
-      float* p = partials + ((int64_t)rbi * C + chain) * (dr + 2);
-      p[0] = v;
-      p[1] = 0.f;   // S1 comes from the packed data sums (finalize)
-    }
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = cbase + 8 * (i >> 2) + 4 * h + (i & 3);
-        if (c < C && 32 * ft + cn < dr) partials[((int64_t)rbi * C + c) * (dr + 2) + 2 + 32 * ft + cn] = G[ft][i];
       }
   }
 }
@@ -960,39 +718,6 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   return BVI_OK;
 }
 
-template <int NW>
-static int launch_f16w(const unsigned char* pk, int64_t n, int d, const float* theta, int c, float* logp, float* grad,
-                       float* ws, hipStream_t s) {
-  constexpr int cpb = 32 * NW;
-  constexpr int max_blocks = NW == 8 ? kMaxRowBlocks : 2 * kMaxRowBlocks;
-  const int ncb = bvi_ceil_div(c, cpb);
-  int per8 = (max_blocks / 8) / ncb;
-  if (per8 < 1) per8 = 1;
-  const int nrb = 8 * per8;
-  float* ublk = ws + (size_t)nrb * c * (d + 2);
-  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * 64 + 2 * kTileRows * 4);
-  static bool lds_ok[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return BVI_ERR_ARG;
-  if (!lds_ok[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)&linreg_f16w_kernel<NW>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    lds_ok[dev] = true;
-  }
-  hipLaunchKernelGGL((linreg_f16w_kernel<NW>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb, ws,
-                     ublk);
-  BVI_HIP_CHECK_LAUNCH();
-  if (c > 256)
-    hipLaunchKernelGGL(linreg_f16_finalize<4>, dim3(c), dim3(256), 0, s, (const float*)ws, (const float*)ublk, cpb,
-                       nrb, n, d, pk, theta, c, logp, grad);
-  else
-    hipLaunchKernelGGL(linreg_f16_finalize<16>, dim3(c), dim3(1024), 0, s, (const float*)ws, (const float*)ublk, cpb,
-                       nrb, n, d, pk, theta, c, logp, grad);
-  BVI_HIP_CHECK_LAUNCH();
-  return BVI_OK;
-}
-
 int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
                           float* grad, float* ws, hipStream_t s) {
   if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
@@ -1006,9 +731,6 @@ int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* the
   if (c <= 64)
     return wide ? launch_f16<64, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s)
                 : launch_f16<32, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s);
-  static const int exp_mode = getenv("BVI_F16_MODE") ? atoi(getenv("BVI_F16_MODE")) : 0;
-  if (wide && c > 128 && exp_mode == 1) return launch_f16w<8>(pk, n, d, theta, c, logp, grad, ws, s);
-  if (wide && c > 64 && c <= 128 && exp_mode == 1) return launch_f16w<4>(pk, n, d, theta, c, logp, grad, ws, s);
   if (c <= 128)
     return wide ? launch_f16<64, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s)
                 : launch_f16<32, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s);
