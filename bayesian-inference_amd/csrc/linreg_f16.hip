@@ -10,8 +10,12 @@
 // and the finalize kernel applies these corrections in double, with X^T X (D x D) taken once, in
 // double, at pack time.  (They are 2^-22-sized; a third piece product xh.w3 did the same job at the
 // price of one more MFMA per tile and chain block: 6.5 ms against 5.8 ms at the headline shape.)
-// Gradient GEMM, 3 products: R = rh + rl times X: rh.xh, rl.xh, rh.xl.
-// 6 f16 products where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3 products) needs 9, on two
+// Gradient GEMM, 2 products: R = rh + rl times the high plane only: rh.xh, rl.xh.  The low plane's share,
+// sum_i xl_if r_i, is linear in the data for a given chain, so it too is known in closed form:
+//   (XL^T y)_f - b0 (XL^T 1)_f - sum_g (X^T XL)_gf w_g
+// with XL^T y, XL^T 1 and X^T XL (D x D) taken once, in double, at pack time (they are 2^-12-sized sums of rounding
+// residues: no cancellation to speak of).  The product rh.xl did the same job: 5.8 ms against 5.1 ms.
+// 5 f16 products where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3 products) needs 9, on two
 // 2-byte planes of X (= the size of the f32 matrix) instead of three.
 // Same likelihood node as there: tfd.Normal(beta_0 + X w, scale)
 // (bayes_vi/model/model.py:194-203, README.md:754-756).
@@ -36,6 +40,7 @@
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
 //   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
 //   gram   [64][64] double: X^T X (rows / columns beyond the model's features are zero)
+//   low    [64][64] double: X^T XL, then double[64] XL^T y, double[64] XL^T 1 (XL: the low plane in x's scale)
 //   planes [2][n_pad][D] f16: hi(x'), lo(x')           (D = 32 or 64 >= the model's feature count; padding
 //                                                       rows and columns are zero)
 //   y      [n_pad] f32                                 (0 for padding rows)
@@ -62,7 +67,9 @@ namespace {
 
 constexpr int kTileRows = 128;             // rows staged per barrier; processed as 64-row halves
 constexpr int kGramOffset = 1024;                       // X^T X, [64][64] double, behind the Header struct
-constexpr int kHeader = kGramOffset + 64 * 64 * 8;      // everything in front of the planes
+constexpr int kLowOffset = kGramOffset + 64 * 64 * 8;   // X^T XL [64][64], XL^T y [64], XL^T 1 [64], double
+constexpr int kLowStride = 64 * 64 + 128;
+constexpr int kHeader = kLowOffset + kLowStride * 8;    // everything in front of the planes
 constexpr int kMaxRowBlocks = 256;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -279,17 +286,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         al[slot][ks] = *reinterpret_cast<const f16x8*>(base + IMG + off);
       }
     };
-    f16x8 xh[3], xl[3];
+    f16x8 xh[3];
     auto load_x = [&](int m, int ft, int slot) {
       const int trow = ro + 32 * m + 4 * g + (ln >> 2);   // swz(trow + 16) == swz(trow)
       const int off0 = trow * SA + (((2 * ft + ((ln & 3) >> 1)) ^ swz(trow)) << 4) + 8 * (ln & 1);
       const int off1 = off0 + 16 * SA;
       const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
       const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
-      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + IMG + off0));
-      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + IMG + off1));
       xh[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-      xl[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     // GEMM1, then r' = z' (u / t) + (u y - u b0): scaled residuals of this wave's 64 rows x 32 chains
     load_a(0, 0);
@@ -319,7 +323,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int i = 0; i < 4; ++i) Z[rt][ct][i] = fmaf(z[ct][i], c1[ct], fmaf(mv[i], nb0[ct], yv[i]));
     }
-    // GEMM2: G' += R'^T X' over the two 32-row pairs
+    // GEMM2: G' += R'^T Xh' over the two 32-row pairs (the low plane's share is added in closed form by the
+    // finalize kernel)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       f16x8 rh[CT], rl[CT];
@@ -346,7 +351,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int ct = 0; ct < CT; ++ct) {
           G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ct], xh[cur], G[ct][ft], 0, 0, 0);
           G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl[ct], xh[cur], G[ct][ft], 0, 0, 0);
-          G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ct], xl[cur], G[ct][ft], 0, 0, 0);
         }
       }
     }
@@ -547,6 +551,84 @@ __global__ void f16_gram_final(const double* __restrict__ gpart, int nblk, int D
   gram[e] = s;
 }
 
+// The low plane's share of the gradient in closed form: with xl = what the low plane holds of x (original scale),
+// sum_i xl_if r_i = (XL^T y)_f - b0 (XL^T 1)_f - sum_g (X^T XL)_gf w_g.  Stage 1, as f16_gram_kernel: block b takes
+// the 64-row tiles b, b + nblk, ...; partials [nblk][kLowStride] = X^T XL [g][f], then XL^T y, then XL^T 1.
+template <int D>
+__global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ X, const float* __restrict__ y,
+                                                      int64_t n, int dr, const Header* __restrict__ hdr,
+                                                      double* __restrict__ lpart) {
+  constexpr int E = D / 16;
+  __shared__ float xt[64][D + 1], lt[64][D + 1], yt[64];
+  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+  double acc[E][E], vy[E], v1[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    vy[i] = 0.0;
+    v1[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) acc[i][j] = 0.0;
+  }
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * D; e += 256) {
+      const int r = e / D, col = e - r * D;
+      const int64_t row = t * 64 + r;
+      const float v = (row < n && col < dr) ? X[row * dr + col] : 0.f;
+      const float q = v * hdr->colscale[col];          // the pack kernel's split, still in the column's scale
+      const _Float16 hi = (_Float16)q;
+      xt[r][col] = v;
+      lt[r][col] = (float)(_Float16)(q - (float)hi);
+    }
+    if (threadIdx.x < 64) yt[threadIdx.x] = t * 64 + threadIdx.x < n ? y[t * 64 + threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) {
+      double xa[E], lb[E];
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        xa[i] = (double)xt[r][E * a + i];
+        lb[i] = (double)lt[r][E * b + i];
+      }
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[i][j] = fma(xa[i], lb[j], acc[i][j]);
+      if (a == 0) {
+        const double yr = (double)yt[r];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+          vy[j] = fma(lb[j], yr, vy[j]);
+          v1[j] += lb[j];
+        }
+      }
+    }
+  }
+  double* out = lpart + (int64_t)blockIdx.x * kLowStride;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const float cs = hdr->colscale[E * b + j];
+    const double inv = cs > 0.f ? 1.0 / (double)cs : 0.0;     // back to the original scale: exact, a power of two
+#pragma unroll
+    for (int i = 0; i < E; ++i) out[(E * a + i) * 64 + E * b + j] = acc[i][j] * inv;
+    if (a == 0) {
+      out[4096 + E * b + j] = vy[j] * inv;
+      out[4096 + 64 + E * b + j] = v1[j] * inv;
+    }
+  }
+}
+
+// stage 2: fixed-order sum of the partials; entries beyond the model's features are zero
+__global__ void f16_low_final(const double* __restrict__ lpart, int nblk, int D, double* __restrict__ low) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kLowStride) return;
+  const bool in = e < 4096 ? ((e >> 6) < D && (e & 63) < D) : (((e - 4096) & 63) < D);
+  double s = 0.0;
+  if (in)
+    for (int b = 0; b < nblk; ++b) s += lpart[(int64_t)b * kLowStride + e];
+  low[e] = s;
+}
+
 // finalize, one workgroup of kFinGroups waves per chain: fixed-order reduction over row blocks in double (a wave
 // takes every kFinGroups-th row block; consecutive lanes read consecutive sums), undoing the power-of-two scales, the
 // closed-form correction for the part of W that its two f16 pieces do not hold (see the top of this file), S1 from
@@ -560,10 +642,11 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int c = blockIdx.x, q2 = d + 2;
   const int64_t tot = (int64_t)C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  __shared__ double part[kFinGroups][64];
-  __shared__ double sums[66], dw[64], gc[64], corr[64];
+  __shared__ double part[kFinGroups][64], part2[kFinGroups][64];
+  __shared__ double sums[66], dw[64], wk[64], gc[64], corr[64];
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
+  const double* low = reinterpret_cast<const double*>(packed + kLowOffset);
   const float* th = theta + (int64_t)c * q2;
   if (grp == 0) {
     // dw_f = w_f - (what the kernel's two pieces of the scaled weight stand for), recomputed with the kernel's
@@ -579,6 +662,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     const _Float16 lo = (_Float16)(q - (float)hi);
     const float rem = (q - (float)hi) - (float)lo;
     dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;
+    wk[o] = o < d ? (double)th[1 + o] - dw[o] : 0.0;     // the weights the kernel's residuals are taken at
   }
   for (int q0 = 0; q0 < q2; q0 += 64) {
     const int q = q0 + o;
@@ -599,18 +683,27 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   {
-    double cf = 0.0;                                                             // (X^T X dw)_f, X^T X symmetric:
-    if (o < d)                                                                   // a wave takes every kFinGroups-th g
-      for (int g = grp; g < d; g += kFinGroups) cf = fma(gram[g * 64 + o], dw[g], cf);
+    double cf = 0.0, cl = 0.0;     // (X^T X dw)_f (X^T X symmetric) and (XL^T X wk)_f: a wave takes every
+    if (o < d)                     // kFinGroups-th g
+      for (int g = grp; g < d; g += kFinGroups) {
+        cf = fma(gram[g * 64 + o], dw[g], cf);
+        cl = fma(low[g * 64 + o], wk[g], cl);
+      }
     part[grp][o] = cf;
+    part2[grp][o] = cl;
   }
   __syncthreads();
   if (threadIdx.x < d) {
     const int f = threadIdx.x;
     const double cs = (double)hdr->colscale[f];
-    const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;   // G'_f = u s_f G_f
-    double cf = part[0][f];
-    for (int w = 1; w < kFinGroups; ++w) cf += part[w][f];
+    double cf = part[0][f], cl = part2[0][f];
+    for (int w = 1; w < kFinGroups; ++w) {
+      cf += part[w][f];
+      cl += part2[w][f];
+    }
+    // G'_f = u s_f (gradient sum over the high plane), plus the low plane's share in closed form
+    const double g0 = (cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0) +
+                      (low[4096 + f] - (double)th[0] * low[4096 + 64 + f] - cl);
     gc[f] = g0;
     corr[f] = cf;
     if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - cf) * inv2);
@@ -645,7 +738,7 @@ size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
 size_t bvi_linreg_f16_pack_scratch(int d) {
   const int dp = plane_cols(d);
   return (size_t)kStatBlocks * (dp + 1) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
-         (size_t)kGramBlocks * 64 * 64 * sizeof(double) + 16;
+         (size_t)kGramBlocks * (64 * 64 + kLowStride) * sizeof(double) + 16;
 }
 
 int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,
@@ -657,8 +750,10 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   const int64_t np = pad_rows(n);
   double* psum = (double*)scratch;
   double* gpart = psum + (size_t)kStatBlocks * (dp + 1);
-  float* pmax = (float*)(gpart + (size_t)kGramBlocks * 64 * 64);
+  double* lpart = gpart + (size_t)kGramBlocks * 64 * 64;
+  float* pmax = (float*)(lpart + (size_t)kGramBlocks * kLowStride);
   double* gram = (double*)((unsigned char*)packed + kGramOffset);
+  double* low = (double*)((unsigned char*)packed + kLowOffset);
   const int64_t total = np * (dp / 8);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
@@ -669,14 +764,18 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
                        kStatBlocks, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
     hipLaunchKernelGGL(f16_gram_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
+    hipLaunchKernelGGL(f16_low_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
   } else {
     hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
     hipLaunchKernelGGL(f16_header_kernel<32>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
                        kStatBlocks, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
     hipLaunchKernelGGL(f16_gram_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
+    hipLaunchKernelGGL(f16_low_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
   }
   hipLaunchKernelGGL(f16_gram_final, dim3(16), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp, gram);
+  hipLaunchKernelGGL(f16_low_final, dim3((kLowStride + 255) / 256), dim3(256), 0, s, (const double*)lpart, kGramBlocks,
+                     dp, low);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
