@@ -67,8 +67,8 @@ namespace {
 
 constexpr int kTileRows = 128;             // rows staged per barrier; processed as 64-row halves
 constexpr int kGramOffset = 1024;                       // X^T X, [64][64] double, behind the Header struct
-constexpr int kLowOffset = kGramOffset + 64 * 64 * 8;   // X^T XL [64][64], XL^T y [64], XL^T 1 [64], double
-constexpr int kLowStride = 64 * 64 + 128;
+constexpr int kLowOffset = kGramOffset + 64 * 64 * 8;   // A [64][64], Bt [64][64], XR^T y [64], XR^T 1 [64], double
+constexpr int kLowStride = 2 * 64 * 64 + 128;
 constexpr int kHeader = kLowOffset + kLowStride * 8;    // everything in front of the planes
 constexpr int kMaxRowBlocks = 256;
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int FT = D / 16;   // feature tiles of GEMM2
   constexpr int SA = 2 * D;    // LDS row stride: no padding, 16-B chunks XOR-swizzled by row (swz below)
   constexpr int IMG = kTileRows * SA;
-  constexpr int BUF = 2 * IMG + 2 * kTileRows * 4;   // two planes, u*y, u*valid
+  constexpr int BUF = IMG + 2 * kTileRows * 4;       // the plane, u*y, u*valid
   constexpr int TPR = D / 8;
   constexpr int NT = 64 * NW;
   constexpr int NCH = kTileRows * TPR;               // 16-B chunks of one plane of a tile
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
   const int64_t n_pad = ntiles * kTileRows;
   const unsigned char* planes = packed + kHeader;
-  const unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
+  const unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
 
   // scaled -W fragments in two f16 pieces; per chain: c1 = u / t and nb0 = -b0
   f16x8 w1[CT][KS], w2[CT][KS];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // {0-3,12-15,20-27}, ...: 16 rows, two neighbouring chunks), the transposed ds_read_b64_tr_b16 (32 lanes:
   // 8 rows x 32 B) and the 128-bit row stores all spread over the 64 banks without conflicts
   auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
-  s16x8 xp[2][PER];
+  s16x8 xp[PER];
   float yp, mp;
   auto gload = [&](int64_t tile) {
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
@@ -230,9 +230,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int e = 0; e < PER; ++e) {
       const int idx = tid + e * NT;
       const int srow = (NCH % NT == 0 || idx < NCH) ? idx / TPR : 0, ch = idx % TPR;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        xp[i][e] = *reinterpret_cast<const s16x8*>(planes + (((int64_t)i * n_pad + row0 + srow) * D + ch * 8) * 2);
+      xp[e] = *reinterpret_cast<const s16x8*>(planes + ((row0 + srow) * D + ch * 8) * 2);
     }
     // every thread stages a y (NW threads per row, same value): an unconditional use keeps the
     // compiler from sinking this load down to the store, where its latency would be exposed
@@ -245,14 +243,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int e = 0; e < PER; ++e) {
       const int idx = tid + e * NT;
       const int srow = idx / TPR, ch = idx % TPR;
-      if (NCH % NT == 0 || idx < NCH) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<s16x8*>(base + i * IMG + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[i][e];
-      }
+      if (NCH % NT == 0 || idx < NCH)
+        *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
     }
-    *reinterpret_cast<float*>(base + 2 * IMG + (tid / YT) * 4) = yp * u;
-    *reinterpret_cast<float*>(base + 2 * IMG + kTileRows * 4 + (tid / YT) * 4) = mp;
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yp * u;
+    *reinterpret_cast<float*>(base + IMG + kTileRows * 4 + (tid / YT) * 4) = mp;
   };
 
   int64_t tile = rbi;
@@ -277,13 +272,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     f32x4v Z[4][CT];
     // LDS fragments are fetched one step ahead of the MFMAs that consume them (the scheduler
     // barriers keep the fetches where they are written), so that their latency is not exposed
-    f16x8 ah[2][KS], al[2][KS];
+    f16x8 ah[2][KS];
     auto load_a = [&](int rt, int slot) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (ro + 16 * rt + ln) * SA + (((4 * ks + g) ^ swz(16 * rt + ln)) << 4);
         ah[slot][ks] = *reinterpret_cast<const f16x8*>(base + off);
-        al[slot][ks] = *reinterpret_cast<const f16x8*>(base + IMG + off);
       }
     };
     f16x8 xh[3];
@@ -299,8 +293,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     load_a(0, 0);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const f32x4v yv = *reinterpret_cast<const f32x4v*>(base + 2 * IMG + (ro + 16 * rt + 4 * g) * 4);
-      const f32x4v mv = *reinterpret_cast<const f32x4v*>(base + 2 * IMG + kTileRows * 4 + (ro + 16 * rt + 4 * g) * 4);
+      const f32x4v yv = *reinterpret_cast<const f32x4v*>(base + IMG + (ro + 16 * rt + 4 * g) * 4);
+      const f32x4v mv = *reinterpret_cast<const f32x4v*>(base + IMG + kTileRows * 4 + (ro + 16 * rt + 4 * g) * 4);
       if (rt < 3) load_a(rt + 1, (rt + 1) & 1);
       else { load_x(0, 0, 0); load_x(0, 1, 1); }
       __builtin_amdgcn_sched_barrier(0);
@@ -314,7 +308,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
-          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w2[ct][ks], z[ct], 0, 0, 0);
         }
       }
@@ -463,7 +456,7 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
   constexpr int TPR = D / 8;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   unsigned char* planes = packed + kHeader;
-  unsigned char* yplane = planes + (int64_t)2 * n_pad * D * 2;
+  unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
   const int64_t total = n_pad * TPR;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -483,18 +476,10 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
-    f16x8 fh, fl;
+    f16x8 fh;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float q = v[j] * hdr->colscale[scol + j];
-      const _Float16 hi = (_Float16)q;
-      fh[j] = hi;
-      fl[j] = (_Float16)(q - (float)hi);
-    }
-    const int64_t off = (row * D + scol) * 2;
-    const int64_t plane = n_pad * D * 2;
-    *reinterpret_cast<f16x8*>(planes + off) = fh;
-    *reinterpret_cast<f16x8*>(planes + plane + off) = fl;
+    for (int j = 0; j < 8; ++j) fh[j] = (_Float16)(v[j] * hdr->colscale[scol + j]);
+    *reinterpret_cast<f16x8*>(planes + (row * D + scol) * 2) = fh;
     if (scol == 0) *reinterpret_cast<float*>(yplane + row * 4) = ok ? y[row] : 0.f;
   }
 }
@@ -551,23 +536,29 @@ __global__ void f16_gram_final(const double* __restrict__ gpart, int nblk, int D
   gram[e] = s;
 }
 
-// The low plane's share of the gradient in closed form: with xl = what the low plane holds of x (original scale),
-// sum_i xl_if r_i = (XL^T y)_f - b0 (XL^T 1)_f - sum_g (X^T XL)_gf w_g.  Stage 1, as f16_gram_kernel: block b takes
-// the 64-row tiles b, b + nblk, ...; partials [nblk][kLowStride] = X^T XL [g][f], then XL^T y, then XL^T 1.
+// What the f16 plane leaves of X, xr = x - xh (exact in f32), enters every sum linearly, so its effect is known
+// in closed form from four pack-time sums in double (see the top of this file):
+//   A  = X^T X - XH^T XH, accumulated term by term as xh_f xr_g + xr_f x_g (no cancellation), symmetric
+//   Bt[g][f] = sum_i xr_if xh_ig,   XR^T y,   XR^T 1.
+// Stage 1, as f16_gram_kernel: block b takes the 64-row tiles b, b + nblk, ...; partials [nblk][kLowStride] =
+// A, Bt, XR^T y, XR^T 1.  Sums are taken in the columns' scales and brought back at the end (exact: powers of two).
 template <int D>
 __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ X, const float* __restrict__ y,
                                                       int64_t n, int dr, const Header* __restrict__ hdr,
                                                       double* __restrict__ lpart) {
   constexpr int E = D / 16;
-  __shared__ float xt[64][D + 1], lt[64][D + 1], yt[64];
+  __shared__ float xt[64][D + 1], ht[64][D + 1], yt[64];
   const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
-  double acc[E][E], vy[E], v1[E];
+  double accA[E][E], accB[E][E], vy[E], v1[E];
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     vy[i] = 0.0;
     v1[i] = 0.0;
 #pragma unroll
-    for (int j = 0; j < E; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < E; ++j) {
+      accA[i][j] = 0.0;
+      accB[i][j] = 0.0;
+    }
   }
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -576,30 +567,36 @@ __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ 
       const int r = e / D, col = e - r * D;
       const int64_t row = t * 64 + r;
       const float v = (row < n && col < dr) ? X[row * dr + col] : 0.f;
-      const float q = v * hdr->colscale[col];          // the pack kernel's split, still in the column's scale
-      const _Float16 hi = (_Float16)q;
-      xt[r][col] = v;
-      lt[r][col] = (float)(_Float16)(q - (float)hi);
+      const float q = v * hdr->colscale[col];          // the pack kernel's rounding, in the column's scale
+      xt[r][col] = q;
+      ht[r][col] = (float)(_Float16)q;
     }
     if (threadIdx.x < 64) yt[threadIdx.x] = t * 64 + threadIdx.x < n ? y[t * 64 + threadIdx.x] : 0.f;
     __syncthreads();
     for (int r = 0; r < 64; ++r) {
-      double xa[E], lb[E];
+      double xa[E], ha[E], ra[E], xb[E], hb[E], rb[E];
 #pragma unroll
       for (int i = 0; i < E; ++i) {
         xa[i] = (double)xt[r][E * a + i];
-        lb[i] = (double)lt[r][E * b + i];
+        ha[i] = (double)ht[r][E * a + i];
+        ra[i] = xa[i] - ha[i];
+        xb[i] = (double)xt[r][E * b + i];
+        hb[i] = (double)ht[r][E * b + i];
+        rb[i] = xb[i] - hb[i];
       }
 #pragma unroll
       for (int i = 0; i < E; ++i)
 #pragma unroll
-        for (int j = 0; j < E; ++j) acc[i][j] = fma(xa[i], lb[j], acc[i][j]);
+        for (int j = 0; j < E; ++j) {
+          accA[i][j] = fma(ha[i], rb[j], fma(ra[i], xb[j], accA[i][j]));   // A(f = E a + i, g = E b + j)
+          accB[i][j] = fma(ha[i], rb[j], accB[i][j]);                      // Bt[g = E a + i][f = E b + j]
+        }
       if (a == 0) {
         const double yr = (double)yt[r];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-          vy[j] = fma(lb[j], yr, vy[j]);
-          v1[j] += lb[j];
+          vy[j] = fma(rb[j], yr, vy[j]);
+          v1[j] += rb[j];
         }
       }
     }
@@ -607,13 +604,18 @@ __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ 
   double* out = lpart + (int64_t)blockIdx.x * kLowStride;
 #pragma unroll
   for (int j = 0; j < E; ++j) {
-    const float cs = hdr->colscale[E * b + j];
-    const double inv = cs > 0.f ? 1.0 / (double)cs : 0.0;     // back to the original scale: exact, a power of two
+    const float csb = hdr->colscale[E * b + j];
+    const double invb = csb > 0.f ? 1.0 / (double)csb : 0.0;
 #pragma unroll
-    for (int i = 0; i < E; ++i) out[(E * a + i) * 64 + E * b + j] = acc[i][j] * inv;
+    for (int i = 0; i < E; ++i) {
+      const float csa = hdr->colscale[E * a + i];
+      const double inva = csa > 0.f ? 1.0 / (double)csa : 0.0;
+      out[(E * a + i) * 64 + E * b + j] = accA[i][j] * inva * invb;
+      out[4096 + (E * a + i) * 64 + E * b + j] = accB[i][j] * inva * invb;
+    }
     if (a == 0) {
-      out[4096 + E * b + j] = vy[j] * inv;
-      out[4096 + 64 + E * b + j] = v1[j] * inv;
+      out[8192 + E * b + j] = vy[j] * invb;
+      out[8192 + 64 + E * b + j] = v1[j] * invb;
     }
   }
 }
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ 
 __global__ void f16_low_final(const double* __restrict__ lpart, int nblk, int D, double* __restrict__ low) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= kLowStride) return;
-  const bool in = e < 4096 ? ((e >> 6) < D && (e & 63) < D) : (((e - 4096) & 63) < D);
+  const bool in = e < 8192 ? (((e & 4095) >> 6) < D && (e & 63) < D) : (((e - 8192) & 63) < D);
   double s = 0.0;
   if (in)
     for (int b = 0; b < nblk; ++b) s += lpart[(int64_t)b * kLowStride + e];
@@ -642,8 +644,8 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int c = blockIdx.x, q2 = d + 2;
   const int64_t tot = (int64_t)C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  __shared__ double part[kFinGroups][64], part2[kFinGroups][64];
-  __shared__ double sums[66], dw[64], wk[64], gc[64], corr[64];
+  __shared__ double part[kFinGroups][64], part2[kFinGroups][64], part3[kFinGroups][64];
+  __shared__ double sums[66], dw[64], wv[64], gc[64], gdw[64], aw[64], bw[64], cr[64];
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
   const double* low = reinterpret_cast<const double*>(packed + kLowOffset);
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     const _Float16 lo = (_Float16)(q - (float)hi);
     const float rem = (q - (float)hi) - (float)lo;
     dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;
-    wk[o] = o < d ? (double)th[1 + o] - dw[o] : 0.0;     // the weights the kernel's residuals are taken at
+    wv[o] = o < d ? (double)th[1 + o] : 0.0;
   }
   for (int q0 = 0; q0 < q2; q0 += 64) {
     const int q = q0 + o;
@@ -683,35 +685,44 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   {
-    double cf = 0.0, cl = 0.0;     // (X^T X dw)_f (X^T X symmetric) and (XL^T X wk)_f: a wave takes every
-    if (o < d)                     // kFinGroups-th g
+    double cf = 0.0, ca = 0.0, cb = 0.0;   // (X^T X dw)_f, (A w)_f (both matrices symmetric), (B w)_f: a wave takes
+    if (o < d)                             // every kFinGroups-th g
       for (int g = grp; g < d; g += kFinGroups) {
         cf = fma(gram[g * 64 + o], dw[g], cf);
-        cl = fma(low[g * 64 + o], wk[g], cl);
+        ca = fma(low[g * 64 + o], wv[g], ca);
+        cb = fma(low[4096 + g * 64 + o], wv[g], cb);
       }
     part[grp][o] = cf;
-    part2[grp][o] = cl;
+    part2[grp][o] = ca;
+    part3[grp][o] = cb;
   }
   __syncthreads();
   if (threadIdx.x < d) {
     const int f = threadIdx.x;
     const double cs = (double)hdr->colscale[f];
-    double cf = part[0][f], cl = part2[0][f];
+    double cf = part[0][f], ca = part2[0][f], cb = part3[0][f];
     for (int w = 1; w < kFinGroups; ++w) {
       cf += part[w][f];
-      cl += part2[w][f];
+      ca += part2[w][f];
+      cb += part3[w][f];
     }
-    // G'_f = u s_f (gradient sum over the high plane), plus the low plane's share in closed form
-    const double g0 = (cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0) +
-                      (low[4096 + f] - (double)th[0] * low[4096 + 64 + f] - cl);
+    // kernel: r_k = y - b0 - xh.wk, G_k = sum xh r_k (G'_f = u s_f G_k,f).  True residual r = r_k - (xr.w + xh.dw):
+    //   G = G_k - A w - (X^T X) dw + t1,   t1 = XR^T y - b0 XR^T 1
+    const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;
+    const double t1 = low[8192 + f] - (double)th[0] * low[8192 + 64 + f];
     gc[f] = g0;
-    corr[f] = cf;
-    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - cf) * inv2);
+    gdw[f] = cf;
+    aw[f] = ca;
+    bw[f] = cb;
+    cr[f] = t1 - cb;               // sum_i xr_if r_k,i
+    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - ca - cf + t1) * inv2);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     double s2 = sums[0] / (u * u);       // S2' = u^2 S2
-    for (int f = 0; f < d; ++f) s2 += dw[f] * (corr[f] - 2.0 * gc[f]);
+    // S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B w + dw . (X^T X) dw), with B w = t1 - cr
+    for (int f = 0; f < d; ++f)
+      s2 += dw[f] * (gdw[f] - 2.0 * gc[f]) + wv[f] * (aw[f] - 2.0 * cr[f] - 2.0 * bw[f]);
     logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
   } else if (threadIdx.x == 64 && grad) {
@@ -731,7 +742,7 @@ static int plane_cols(int d) { return d <= 32 ? 32 : 64; }
 
 size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
   const int64_t np = pad_rows(n);
-  return (size_t)(kHeader + np * plane_cols(d) * 4 + np * 4);
+  return (size_t)(kHeader + np * plane_cols(d) * 2 + np * 4);
 }
 
 // scratch for the column statistics of the pack step (bytes)
@@ -792,7 +803,7 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   const int nrb = 8 * per8;
   // workspace: partials [nrb][c][d+2], then one residual scale per chain block
   float* ublk = ws + (size_t)nrb * c * (d + 2);
-  const size_t lds = 2 * (size_t)(2 * kTileRows * 2 * D + 2 * kTileRows * 4);
+  const size_t lds = 2 * (size_t)(kTileRows * 2 * D + 2 * kTileRows * 4);
   // > 64 KB of dynamic LDS has to be allowed once per kernel and device (setting it twice from two threads is
   // harmless)
   static bool lds_ok[64] = {};
