@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
 
   // scaled -W fragments in two f16 pieces; per chain: c1 = u / t and nb0 = -b0
-  f16x8 w1[CT][KS], w2[CT][KS];
+  f16x8 w1[CT][KS];
   float nb0[CT], c1[CT];
   float u;
   {
@@ -187,13 +187,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float q = v[ks][j] * t;
-          const _Float16 hi = first_piece(q);
-          const _Float16 lo = (_Float16)(q - (float)hi);
-          w1[ct][ks][j] = hi;
-          w2[ct][ks][j] = lo;       // what is left, (q - hi) - lo, is accounted for in the finalize kernel
-        }
+        for (int j = 0; j < 8; ++j)
+          w1[ct][ks][j] = first_piece(v[ks][j] * t);   // what is left, q - w1, is accounted for in the finalize kernel
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
@@ -308,7 +303,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
-          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w2[ct][ks], z[ct], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -644,15 +638,15 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int c = blockIdx.x, q2 = d + 2;
   const int64_t tot = (int64_t)C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  __shared__ double part[kFinGroups][64], part2[kFinGroups][64], part3[kFinGroups][64];
-  __shared__ double sums[66], dw[64], wv[64], gc[64], gdw[64], aw[64], bw[64], cr[64];
+  __shared__ double part[5][kFinGroups][64];
+  __shared__ double sums[66], dw[64], wv[64], s2t[64];
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
   const double* low = reinterpret_cast<const double*>(packed + kLowOffset);
   const float* th = theta + (int64_t)c * q2;
   if (grp == 0) {
-    // dw_f = w_f - (what the kernel's two pieces of the scaled weight stand for), recomputed with the kernel's
-    // own arithmetic: w'' = -w / s_f * t, pieces hi + lo, remainder exact in f32
+    // dw_f = w_f - (what the kernel's f16 piece of the scaled weight stands for), recomputed with the kernel's
+    // own arithmetic: w'' = -w / s_f * t, piece w1, remainder exact in f32
     const float cs = o < d ? hdr->colscale[o] : 0.f;
     const float v = o < d ? -scaled_weight(th[1 + o], cs) : 0.f;
     float amax = fabsf(v);
@@ -660,9 +654,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     const float t = pow2_scale(amax);
     const float q = v * t;
-    const _Float16 hi = first_piece(q);
-    const _Float16 lo = (_Float16)(q - (float)hi);
-    const float rem = (q - (float)hi) - (float)lo;
+    const float rem = q - (float)first_piece(q);        // exact: the piece is q rounded to a coarser grid
     dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;
     wv[o] = o < d ? (double)th[1 + o] : 0.0;
   }
@@ -673,10 +665,10 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
 #pragma unroll 16
       for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + (int64_t)c * q2 + q];
     }
-    part[grp][o] = s;
+    part[0][grp][o] = s;
     __syncthreads();
     if (grp == 0 && q < q2) {
-      for (int w = 1; w < kFinGroups; ++w) s += part[w][o];
+      for (int w = 1; w < kFinGroups; ++w) s += part[0][w][o];
       sums[q] = s;
     }
     __syncthreads();
@@ -685,44 +677,48 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   {
-    double cf = 0.0, ca = 0.0, cb = 0.0;   // (X^T X dw)_f, (A w)_f (both matrices symmetric), (B w)_f: a wave takes
-    if (o < d)                             // every kFinGroups-th g
+    // (X^T X dw)_f, (A w)_f, (A dw)_f (both matrices symmetric), (B w)_f, (B dw)_f: a wave takes every
+    // kFinGroups-th g
+    double cf = 0.0, caw = 0.0, cad = 0.0, cbw = 0.0, cbd = 0.0;
+    if (o < d)
       for (int g = grp; g < d; g += kFinGroups) {
+        const double am = low[g * 64 + o], bm = low[4096 + g * 64 + o];
         cf = fma(gram[g * 64 + o], dw[g], cf);
-        ca = fma(low[g * 64 + o], wv[g], ca);
-        cb = fma(low[4096 + g * 64 + o], wv[g], cb);
+        caw = fma(am, wv[g], caw);
+        cad = fma(am, dw[g], cad);
+        cbw = fma(bm, wv[g], cbw);
+        cbd = fma(bm, dw[g], cbd);
       }
-    part[grp][o] = cf;
-    part2[grp][o] = ca;
-    part3[grp][o] = cb;
+    part[0][grp][o] = cf;
+    part[1][grp][o] = caw;
+    part[2][grp][o] = cad;
+    part[3][grp][o] = cbw;
+    part[4][grp][o] = cbd;
   }
   __syncthreads();
   if (threadIdx.x < d) {
     const int f = threadIdx.x;
     const double cs = (double)hdr->colscale[f];
-    double cf = part[0][f], ca = part2[0][f], cb = part3[0][f];
-    for (int w = 1; w < kFinGroups; ++w) {
-      cf += part[w][f];
-      ca += part2[w][f];
-      cb += part3[w][f];
+    double m[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      m[k] = part[k][0][f];
+      for (int w = 1; w < kFinGroups; ++w) m[k] += part[k][w][f];
     }
-    // kernel: r_k = y - b0 - xh.wk, G_k = sum xh r_k (G'_f = u s_f G_k,f).  True residual r = r_k - (xr.w + xh.dw):
-    //   G = G_k - A w - (X^T X) dw + t1,   t1 = XR^T y - b0 XR^T 1
+    // kernel: r_k = y - b0 - xh.wk with wk = w - dw, G_k = sum xh r_k (G'_f = u s_f G_k,f).  The true residual is
+    // r = r_k - (xr.w + xh.dw), hence
+    //   G = G_k - A wk - (X^T X) dw + t1,   t1 = XR^T y - b0 XR^T 1
+    //   S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B wk + dw . (X^T X - A) dw),   cr = t1 - B wk
     const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;
     const double t1 = low[8192 + f] - (double)th[0] * low[8192 + 64 + f];
-    gc[f] = g0;
-    gdw[f] = cf;
-    aw[f] = ca;
-    bw[f] = cb;
-    cr[f] = t1 - cb;               // sum_i xr_if r_k,i
-    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - ca - cf + t1) * inv2);
+    const double bwk = m[3] - m[4];
+    s2t[f] = -2.0 * (wv[f] * (t1 - bwk) + dw[f] * g0) + wv[f] * (m[1] - 2.0 * bwk) + dw[f] * (m[0] - m[2]);
+    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - (m[1] - m[2]) - m[0] + t1) * inv2);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     double s2 = sums[0] / (u * u);       // S2' = u^2 S2
-    // S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B w + dw . (X^T X) dw), with B w = t1 - cr
-    for (int f = 0; f < d; ++f)
-      s2 += dw[f] * (gdw[f] - 2.0 * gc[f]) + wv[f] * (aw[f] - 2.0 * cr[f] - 2.0 * bw[f]);
+    for (int f = 0; f < d; ++f) s2 += s2t[f];
     logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
   } else if (threadIdx.x == 64 && grad) {
