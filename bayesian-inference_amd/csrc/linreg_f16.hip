@@ -1,22 +1,26 @@
-// Linear-regression raw sums for many chains on the f16 matrix cores, operands split into f16
-// pieces of range-normalised values (11 significant bits each, plus one from round-to-nearest).
-// Residual GEMM, 3 products: X = xh + xl (error <= 1 f32 ulp, independent from row to row, so it
-// averages out over rows) times W = w1 + w2: xh.w1, xl.w1, xh.w2.  What two f16 pieces leave of W,
-// dw = w - (w1 + w2) ~ 2^-22 w, matters all the same: an error in W is the same for every row, so
-// it acts like evaluating the gradient at a shifted parameter and grows with n, not sqrt(n).  But
-// exactly because it is one vector per chain its effect is known in closed form: the kernel's
-// residuals are r + X dw, hence
-//   G = G_kernel - (X^T X) dw,     S2 = S2_kernel - 2 dw . G_kernel + dw . (X^T X) dw,
-// and the finalize kernel applies these corrections in double, with X^T X (D x D) taken once, in
-// double, at pack time.  (They are 2^-22-sized; a third piece product xh.w3 did the same job at the
-// price of one more MFMA per tile and chain block: 6.5 ms against 5.8 ms at the headline shape.)
-// Gradient GEMM, 2 products: R = rh + rl times the high plane only: rh.xh, rl.xh.  The low plane's share,
-// sum_i xl_if r_i, is linear in the data for a given chain, so it too is known in closed form:
-//   (XL^T y)_f - b0 (XL^T 1)_f - sum_g (X^T XL)_gf w_g
-// with XL^T y, XL^T 1 and X^T XL (D x D) taken once, in double, at pack time (they are 2^-12-sized sums of rounding
-// residues: no cancellation to speak of).  The product rh.xl did the same job: 5.8 ms against 5.1 ms.
-// 5 f16 products where the all-bf16 kernel (linreg_bf16x3.hip, 6 + 3 products) needs 9, on two
-// 2-byte planes of X (= the size of the f32 matrix) instead of three.
+// Linear-regression raw sums for many chains on the f16 matrix cores.  The two contractions over all rows run
+// on f16 operands of range-normalised values (11 significant bits, plus one from round-to-nearest); everything
+// the f16 operands leave out is linear in the data for a given chain and is added in closed form, in double,
+// from sums taken once at pack time -- so the result is that of the full-precision contraction:
+//   kernel (per call, all rows):  r_k,i = y_i - b0 - xh_i . w1          residual GEMM, 1 product (xh: the f16 plane
+//                                 S2_k = sum r_k^2                       of X, w1: one f16 piece of W)
+//                                 G_k  = sum xh_i (rh_i + rl_i)          gradient GEMM, 2 products (R in 2 pieces:
+//                                                                        its rounding residue is not linear in anything)
+//   with xr = x - xh (exact in f32), dw = w - w1 (exact in f32), the true residual is r = r_k - (xr.w + xh.dw), hence
+//   G  = G_k - A (w - dw) - (X^T X) dw + t1                 A = X^T X - XH^T XH,  t1 = XR^T y - b0 XR^T 1
+//   S2 = S2_k - 2 (w . cr + dw . G_k)                        cr = t1 - B (w - dw),  B = XR^T XH
+//        + w . A w - 2 w . B (w - dw) + dw . (X^T X - A) dw
+// with X^T X, A, B (D x D) and XR^T y, XR^T 1 (D) in double behind the header of the packed dataset
+// (f16_gram_kernel, f16_low_kernel; A is accumulated term by term as xh_f xr_g + xr_f x_g, so nothing cancels).
+// xr and dw are 2^-12-sized, so are the corrections: they are error compensation, far from the cancellation a
+// Gram-matrix evaluation of the whole likelihood would suffer -- r_k differs from r by ~2^-12 of the fitted
+// values, and the f32 sums of the kernel stay accurate as long as that is not far above the residuals themselves
+// (signal / noise of several thousand: tests/test_gpu_parity.py).  An error in W is the same for every row, acts
+// like a shifted parameter and grows with n; handled exactly this way it costs nothing per row.
+// History at the headline shape (N = 10M, D = 64, 1024 chains): X, W and R in 2 pieces each with a third piece
+// of W, 7 products, 6.5 ms; dw in closed form, 6 products, 5.8 ms; low plane's share of G in closed form, 5
+// products, 5.1 ms; no low plane at all, 4 products, 4.25 ms; one piece of W, 3 products, 3.6 ms.  The all-bf16
+// kernel (linreg_bf16x3.hip) needs 9 products on three planes.
 // Same likelihood node as there: tfd.Normal(beta_0 + X w, scale)
 // (bayes_vi/model/model.py:194-203, README.md:754-756).
 //
@@ -26,8 +30,8 @@
 //                                                                          0 for an all-zero column)
 //   w''_cd = -w_cd / s_d * t_c,  t_c = 2^(13 - floor(log2 max_d |w_cd / s_d|))  (per chain, per call)
 // so that |x'|, |w''| < 2^14 and z' = sum_d x'_id w''_cd = -t_c x_i.w_c accumulates in f32; the low
-// pieces then sit 2^-11 below, far above the f16 subnormal threshold for every element that
-// matters to the sum.  The residuals are produced already scaled for the gradient GEMM,
+// piece of the residuals then sits 2^-11 below its high piece, far above the f16 subnormal threshold for every
+// element that matters to the sum.  The residuals are produced already scaled for the gradient GEMM,
 //   r'_ic = u r_ic = z'_ic (u / t_c) + (u y_i - u b0_c),
 //   u = min over the workgroup's chains of 2^(14 - floor(log2 (max|y| + |b0_c| + D 2^14 max_d |w_cd / s_d|)))
 // : the bound holds for every row, so |r'| < 2^15, and it is loose by a few binades only, which
@@ -40,8 +44,8 @@
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
 //   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
 //   gram   [64][64] double: X^T X (rows / columns beyond the model's features are zero)
-//   low    [64][64] double: X^T XL, then double[64] XL^T y, double[64] XL^T 1 (XL: the low plane in x's scale)
-//   planes [2][n_pad][D] f16: hi(x'), lo(x')           (D = 32 or 64 >= the model's feature count; padding
+//   low    [64][64] double A, [64][64] double Bt (Bt[g][f] = B_fg), double[64] XR^T y, double[64] XR^T 1
+//   plane  [n_pad][D] f16: x'                          (D = 32 or 64 >= the model's feature count; padding
 //                                                       rows and columns are zero)
 //   y      [n_pad] f32                                 (0 for padding rows)
 //

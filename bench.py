@@ -220,7 +220,7 @@ def main():
         'higher_is_better': True,
         'scaling': 'strong',
         'vs_baseline': None,
-        'dtype': {None: 'f32', _native.PACK_F16: 'f32 (f16 2-piece split MFMA, 5 products + closed-form compensation, f32 accumulate)',
+        'dtype': {None: 'f32', _native.PACK_F16: 'f32 (f16 MFMA on one f16 plane, residuals in 2 pieces; remainders of X and W in exact closed form; f32 accumulate)',
                   _native.PACK_BF16X3: 'f32 (bf16 3-piece split MFMA, f32 accumulate)'}[fmt],
         'data': 'synthetic',
         'config': {'workload': 'Bayesian linear regression, HMC leapfrog gradient evaluations (BASELINE.json configs[1])',

@@ -126,17 +126,15 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
  *   BVI_PACK_BF16X3  d = 32 or 64; three bf16 piece planes [3][n_pad][d] + a 16-B row extension;
  *                    evaluated with precision BF16X6 (default) or BF16X3;
  *   BVI_PACK_F16     1 <= d <= 64; per-column power-of-two scales, data sums and max|y| in a 1024-B
- *                    header, X^T X and X^T XL as [64][64] doubles, XL^T y and XL^T 1 as 64 doubles each (XL:
- *                    the low plane), f16 hi/lo planes [2][n_pad][32 or 64] of the scaled X, zero beyond column d
- *                    (both GEMMs run on the f16 matrix cores; X, the weights and the residuals in 2 pieces each;
- *                    what 2 pieces leave of the weights is one vector per chain whose effect on the sums is
- *                    exactly (X^T X) times it, and the low plane's share of the gradient is
- *                    XL^T y - b0 XL^T 1 - (XL^T X) w: both applied in double after the reduction) + y[n_pad]
- *                    in f32,
- *                    n_pad = n rounded up to 128; precision must be AUTO.  Gradient error at the level of
- *                    the exact-f32 kernel's.  Limits: an element below 2^-16 of its column's largest
- *                    magnitude loses low bits (absolute error <= 2^-39 of that maximum); X is held to
- *                    within 1 f32 ulp, exactly if it has <= 22 significant bits.
+ *                    header, then [64][64] doubles X^T X, A = X^T X - XH^T XH and XR^T XH (transposed), and
+ *                    64 doubles each XR^T y and XR^T 1 (XH: the f16 plane, XR = X - XH, exact), then one f16
+ *                    plane [n_pad][32 or 64] of the scaled X, zero beyond column d, + y[n_pad] in f32;
+ *                    n_pad = n rounded up to 128; precision must be AUTO.  Both contractions over the rows run
+ *                    on the f16 matrix cores (f16 plane times one f16 piece of the weights; residuals in 2
+ *                    pieces times the f16 plane); what the f16 operands leave of X and of the weights enters
+ *                    every sum linearly and is added exactly, in double, from those pack-time sums after the
+ *                    reduction.  Log-density at f32 accuracy, gradient error at the level of the exact-f32
+ *                    kernel's, for residuals down to ~1/5000 of the fitted values.
  * Padding rows are zero (BF16X3: n_pad = n rounded up to 64).  bvi_linreg_pack needs bvi_linreg_pack_scratch_bytes
  * of workspace (0 for BF16X3). */
 #define BVI_PACK_BF16X3 0

@@ -215,6 +215,41 @@ def test_linreg_f16_pieces_at_the_mode_small_weights(nat, ws, gpu_device):
     assert e16 <= 3.0 * e32, (e16, e32)
 
 
+@pytest.mark.parametrize('sigma', [0.1, 0.01, 0.001])
+def test_linreg_f16_pieces_high_signal_to_noise(nat, ws, gpu_device, sigma):
+    """Residuals far smaller than the fitted values (signal / noise up to ~5000), chains at the posterior's own
+    width around the mode.  The kernel streams one f16 plane of X against one f16 piece of W and adds what both
+    leave out in closed form, so its own residuals carry an error of ~2^-12 of the fitted values -- here up to
+    the size of the true residuals -- which the closed form has to remove exactly: the log-density must stay at
+    f32 accuracy and the gradient within a small multiple of the exact-f32 kernel's error (which grows with
+    signal / noise in the same way)."""
+    rng = np.random.default_rng(17)
+    n, d, c = 200000, 64, 40
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    w = rng.normal(size=d)
+    y = (0.5 + X.astype(np.float64) @ w + sigma * rng.normal(size=n)).astype(np.float32)
+    A = np.concatenate([np.ones((n, 1)), X.astype(np.float64)], 1)
+    ols = np.linalg.lstsq(A, y.astype(np.float64), rcond=None)[0]
+    width = sigma / math.sqrt(n)
+    th = np.concatenate([ols[None, :1] + width * rng.normal(size=(c, 1)), ols[None, 1:] + width * rng.normal(size=(c, d)),
+                         sigma * rng.uniform(0.9, 1.1, (c, 1))], -1).astype(np.float32)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
+    lp32, g32 = nat.linreg_logp_grad(dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device), ws,
+                                     precision=nat.PREC_F32)
+    scale = np.abs(ref_g[:, 1:1 + d]).max(-1, keepdims=True)
+    e16 = (np.abs(g - ref_g)[:, 1:1 + d] / scale).max()
+    e32 = (np.abs(g32.cpu().numpy() - ref_g)[:, 1:1 + d] / scale).max()
+    assert e16 <= 2.0 * e32 + 1e-6, (e16, e32)
+    assert (np.abs(lp - ref_lp) / np.abs(ref_lp)).max() <= 2e-6        # 1e-5 bar with room to spare
+    # d logp / d scale = -n / s + S2 / s^3 is a difference of two equal terms at the mode, so it shows the error of
+    # S2 itself; any f32 evaluation rounds the fitted values to ~1e-7 of their size, which is ~1e-3 of a residual
+    # at signal / noise 5000 and averages down with sqrt(n): the exact-f32 kernel sets the scale here too
+    gs = (np.abs(g[:, d + 1] - ref_g[:, d + 1]) / (n / th[:, d + 1])).max()
+    gs32 = (np.abs(g32.cpu().numpy()[:, d + 1] - ref_g[:, d + 1]) / (n / th[:, d + 1])).max()
+    assert gs <= 2.0 * gs32 + 1e-6, (gs, gs32)
+
+
 def test_linreg_f16_pieces_column_ranges(nat, ws, gpu_device):
     """Columns six decades apart in scale, off-centre, one heavy-tailed, one constant, one all zero;
     targets in the hundreds: the per-column / per-chain / residual scales must absorb all of it."""
