@@ -477,7 +477,7 @@ size_t bvi_ws_linreg(int64_t n, int c, int d) {
     const int nb2 = bvi_linreg_bf16x3_blocks(n, c);
     nb = nb2 > nb ? nb2 : nb;
   }
-  nb = nb < 513 ? 513 : nb;     // the f16-piece kernel: up to 512 row blocks + one scale per chain block
+  nb = nb < 769 ? 769 : nb;     // the f16-plane kernel: up to 768 row blocks + one scale per chain block
   return (size_t)nb * c * (d + 2) * sizeof(float);
 }
 

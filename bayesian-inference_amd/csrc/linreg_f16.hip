@@ -131,7 +131,7 @@ __device__ __forceinline__ void split_pair(float q0, float q1, unsigned& hi, uns
 }
 
 template <int D, int NW, int CT>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 3 : 2, CT == 1 ? 3 : 2))) void linreg_f16_kernel(
     const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
     int nrb, float* __restrict__ partials, float* __restrict__ ublk) {
   // D: feature count of the packed planes (32 or 64); dr <= D: the model's feature count (columns dr .. D-1
@@ -796,7 +796,9 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
                       float* ws, hipStream_t s) {
   constexpr int cpb = 16 * CT * NW;
   // NW = 8: one workgroup per CU; NW = 4 (at most 128 chains): two per CU, each on its own row blocks
-  constexpr int max_blocks = NW == 8 ? kMaxRowBlocks : 2 * kMaxRowBlocks;
+  // (one tile per wave: three per CU on a large dataset -- the kernel is then bound by its own HBM stream, and
+  // a third workgroup's loads in flight are worth 3 - 5 %; a mid-size dataset has too few tiles for that)
+  const int max_blocks = NW == 8 ? kMaxRowBlocks : ((CT == 1 && n >= 1000000) ? 3 : 2) * kMaxRowBlocks;
   const int ncb = bvi_ceil_div(c, cpb);
   int per8 = (max_blocks / 8) / ncb;
   if (per8 < 1) per8 = 1;
