@@ -90,6 +90,25 @@ def test_regression_10m_rows_1024_chains_against_float64_statistics(nat, ws, reg
     r['full'] = (lp, g)
 
 
+@pytest.mark.parametrize('c', [1, 4, 16, 64])
+def test_regression_10m_rows_few_chains_through_the_host_mirror(nat, ws, regression_10m, c):
+    """From a million rows on the host mirror routes every number of chains to the f16-plane kernel (one chain
+    tile per wave, three workgroups per CU): same reference, same bar as for 1024 chains."""
+    from bayes_vi_amd.fused_target import LinearRegression
+    r = regression_10m
+    th = r['th'][100:100 + c].contiguous()
+    if 'lik' not in r:
+        r['lik'] = LinearRegression(r['X'], r['y'])
+    lik = r['lik']
+    assert lik.matrix_core_format(c) == nat.PACK_F16
+    lp, g = lik.logp_grad(th)
+    ref_lp, ref_g, term = _reference_from_stats(r, th)
+    _close(lp, ref_lp, ref_lp.abs(), what='logp')
+    _close(g, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='grad')
+    lp_v, _ = lik.logp_grad(th, want_grad=False)
+    assert torch.equal(lp, lp_v)
+
+
 def test_regression_10m_row_shards_add(nat, ws, regression_10m):
     """The outputs are likelihood-only sums, so two row shards -- packed separately, with their own
     column scales -- must add up to the full-data result (what the all-reduce over GPUs relies on)."""
