@@ -257,9 +257,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += nrb) {
-#ifndef ABL_NOSYNC
     gload(tile + nrb);   // past the end: re-reads tile 0, never used
-#endif
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* base = lds + buf * BUF;
     float a2[CT];               // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
@@ -348,11 +346,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) s2[ct] += a2[ct];
-#ifndef ABL_NOSYNC
     lstore(buf ^ 1);     // as late as possible: the whole tile's arithmetic covers the HBM latency of gload
     __syncthreads();
     buf ^= 1;
-#endif
   }
 
 #pragma unroll
