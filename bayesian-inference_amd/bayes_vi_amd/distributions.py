@@ -202,6 +202,35 @@ class MultivariateNormalTriL(Distribution):
         return self.loc + (torch.tril(self.scale_tril) @ eps[..., None])[..., 0]
 
 
+class MultivariateNormalDiag(Distribution):
+    """Independent normals over the last axis, tfd.MultivariateNormalDiag(loc, scale_diag): what the reference's
+    experiments return from `posterior_lift_distribution` (linear-regression-example.ipynb cell 13) and use as a
+    trainable flow base (README.md:668).  Differentiable in loc and scale_diag."""
+
+    def __init__(self, loc=None, scale_diag=None, name='MultivariateNormalDiag'):
+        self.loc, self.scale_diag, self.name = _t(loc), _t(scale_diag), name
+
+    @property
+    def event_shape(self):
+        return torch.broadcast_shapes(self.loc.shape, self.scale_diag.shape)[-1:]
+
+    @property
+    def batch_shape(self):
+        return torch.broadcast_shapes(self.loc.shape, self.scale_diag.shape)[:-1]
+
+    def log_prob(self, x):
+        sc = _on(self.scale_diag, x.device)
+        z = (x - _on(self.loc, x.device)) / sc
+        return (-0.5 * z * z - 0.5 * LN2PI - torch.log(sc.abs())).sum(-1)
+
+    log_prob_flat = log_prob
+
+    def sample(self, sample_shape=(), generator=None):
+        shape = tuple(sample_shape) + tuple(torch.broadcast_shapes(self.loc.shape, self.scale_diag.shape))
+        eps = torch.randn(shape, generator=generator).to(self.loc.device)
+        return self.loc + self.scale_diag * eps
+
+
 class MixtureSameFamily(Distribution):
     def __init__(self, mixture_distribution, components_distribution, name='MixtureSameFamily'):
         self.mixture_distribution = mixture_distribution

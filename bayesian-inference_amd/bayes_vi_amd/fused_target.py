@@ -344,7 +344,10 @@ class _TargetLogProbFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         g, = ctx.saved_tensors
-        return grad_out[:, None] * g, None
+        # a sample whose discrepancy was dropped as non-finite (vi.py:55-58) arrives with weight 0 and may carry a
+        # non-finite gradient: it must contribute nothing, not 0 * inf
+        w = grad_out[:, None]
+        return torch.where(w == 0, torch.zeros_like(g), w * g), None
 
 
 def differentiable_log_prob(posterior: Posterior, theta):

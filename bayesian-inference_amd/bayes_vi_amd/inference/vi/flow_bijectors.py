@@ -43,6 +43,34 @@ def make_shift_fn(event_ndims, hidden_layers=None):
     return _mlp(event_ndims, hidden_layers or [32], event_ndims, _ReLU6, None)
 
 
+class Chain(Bijector, nn.Module):
+    """Composition of trainable flow bijectors with tfb.Chain's order: `forward` applies the LAST bijector of the
+    list first (the reference stacks Hamiltonian flows this way, linear-regression-example.ipynb cell 13)."""
+
+    def __init__(self, bijectors, name='chain'):
+        nn.Module.__init__(self)
+        self.bijectors = nn.ModuleList(bijectors) if all(isinstance(b, nn.Module) for b in bijectors) \
+            else list(bijectors)
+        self.name = name
+
+    def forward(self, x):
+        for b in reversed(list(self.bijectors)):
+            x = b.forward(x)
+        return x
+
+    def inverse(self, y):
+        for b in self.bijectors:
+            y = b.inverse(y)
+        return y
+
+    def forward_log_det_jacobian(self, x):
+        total = x.new_zeros(x.shape[:-1])
+        for b in reversed(list(self.bijectors)):
+            total = total + b.forward_log_det_jacobian(x)
+            x = b.forward(x)
+        return total
+
+
 class HamiltonianFlow(Bijector, nn.Module):
     """Volume-preserving flow: n leapfrog steps of a (trainable) separable Hamiltonian on the
     augmented state [q | p]; inverse = the same integration with negated step sizes;

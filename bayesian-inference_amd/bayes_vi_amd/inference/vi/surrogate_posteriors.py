@@ -18,6 +18,20 @@ def _softplus_inverse(x):
     return x + torch.log(-torch.expm1(-x))
 
 
+def _modules_reachable_from(fn):
+    """nn.Modules a callable is, or closes over (one level of closure cells and default arguments)."""
+    if fn is None:
+        return []
+    if isinstance(fn, nn.Module):
+        return [fn]
+    found = []
+    cells = [c.cell_contents for c in (getattr(fn, '__closure__', None) or ()) if c is not None]
+    for obj in cells + list(getattr(fn, '__defaults__', None) or ()):
+        if isinstance(obj, nn.Module) and not any(obj is f for f in found):
+            found.append(obj)
+    return found
+
+
 class SurrogatePosterior(nn.Module):
     """Base class (surrogate_posteriors.py:10-94)."""
 
@@ -32,6 +46,12 @@ class SurrogatePosterior(nn.Module):
         else:
             raise ValueError('Model has incompatible dtypes: {}'.format(set(dtypes)))
         self.extra_ndims = 0
+
+    def base_noise(self, n, dim):
+        """Standard-normal draws [n, dim] that the reparameterised sampler transforms.  Tests replace this attribute
+        to evaluate a step on injected noise."""
+        dev = next((p.device for p in self.parameters()), torch.device('cpu'))
+        return torch.randn(n, dim, device=dev, dtype=torch.float32)
 
     # reshape_sample_bijector.forward: flat constrained sample -> list of named parts
     def reshape_sample(self, q):
@@ -95,7 +115,7 @@ class ADVI(SurrogatePosterior):
 
     def sample_unconstrained(self, n):
         pu = self.unconstrained_event_ndims
-        eps = torch.randn(n, pu, device=self.loc.device, dtype=self.loc.dtype)
+        eps = self.base_noise(n, pu)
         if self.mean_field:
             sc = F.softplus(self.raw_scale)
             z = self.loc + sc * eps
@@ -121,23 +141,22 @@ class NormalizingFlow(SurrogatePosterior):
         self.extra_ndims = extra_ndims if extra_ndims else 0
         self.base_distribution = base_distribution       # object with sample_and_log_prob(n) or None
         self.posterior_lift_distribution = posterior_lift_distribution
+        # the reference trains every variable the loss touches (tape.watched_variables(), vi.py:69), which includes
+        # networks a lift callable closes over (linear-regression-example.ipynb cell 13): register them here so that
+        # `parameters()` finds them
+        self.lift_networks = nn.ModuleList(_modules_reachable_from(posterior_lift_distribution))
 
     def posterior_lift_log_prob(self, z, a):
         if self.posterior_lift_distribution is not None:
             return self.posterior_lift_distribution(z).log_prob(a)
         return (-0.5 * a * a - 0.5 * LN2PI).sum(-1)
 
-    def _device(self):
-        for p in self.parameters():
-            return p.device
-        return torch.device('cpu')
-
     def sample_unconstrained(self, n):
         dim = self.unconstrained_event_ndims + self.extra_ndims
         if self.base_distribution is not None:
             x, logp = self.base_distribution.sample_and_log_prob(n)
         else:
-            x = torch.randn(n, dim, device=self._device())
+            x = self.base_noise(n, dim)
             logp = (-0.5 * x * x - 0.5 * LN2PI).sum(-1)
         u = self.flow_bijector.forward(x)
         return u, logp - self.flow_bijector.forward_log_det_jacobian(x)

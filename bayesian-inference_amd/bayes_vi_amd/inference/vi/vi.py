@@ -11,6 +11,42 @@ def kl_reverse(logu):
     return -logu
 
 
+class _AdamState:
+    """The update of tf.optimizers.Adam (the optimizer `VI.fit` defaults to, vi.py:77) on torch parameters:
+        m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2
+        lr_t = lr sqrt(1 - b2^t) / (1 - b1^t);  x <- x - lr_t m / (sqrt(v) + epsilon)
+    (epsilon sits outside the bias correction, unlike torch.optim.Adam).  The step counter lives on the
+    parameters' device and nothing here reads it back, so a step can be recorded in a HIP graph."""
+
+    def __init__(self, params, lr, betas, eps):
+        self.params = list(params)
+        self.lr, (self.b1, self.b2), self.eps = lr, betas, eps
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        self.t = torch.zeros((), dtype=torch.float64, device=dev)
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self, set_to_none=False):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        lr_t = (self.lr * torch.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)).to(torch.float32)
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = p.grad
+            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+            p.sub_(lr_t * m / (v.sqrt() + self.eps))
+
+
 class Adam:
     """Optimizer description with the reference's spelling, tf.optimizers.Adam(learning_rate=...);
     bound to the surrogate's parameters when `VI.fit` starts."""
@@ -19,8 +55,7 @@ class Adam:
         self.learning_rate, self.betas, self.eps = learning_rate, (beta_1, beta_2), epsilon
 
     def bind(self, params, capturable=False):
-        return torch.optim.Adam(params, lr=self.learning_rate, betas=self.betas, eps=self.eps,
-                                capturable=capturable)
+        return _AdamState(params, self.learning_rate, self.betas, self.eps)
 
 
 class VI(Inference):

@@ -239,3 +239,147 @@ def test_fullcov_mixture_1m_rows_shards_add(nat, ws, gpu_device):
     for lo, hi in ((0, k), (k, k + k * d), (k + k * d, th.shape[1])):
         scale = gr[:, lo:hi].abs().max(-1, keepdim=True).values.double()
         _close((a[1].double() + b[1].double())[:, lo:hi], gr[:, lo:hi], scale, rtol=3 * RTOL, what='fullcov grad shards')
+
+
+# ---- BASELINE.json configs[4]: ELBO gradients on the 10M x 64 regression with 256 Monte-Carlo samples ----
+def _vi_setup(r, gpu_device, rows=None):
+    import collections
+    import bayes_vi_amd.distributions as tfd
+    from bayes_vi_amd import symbolic
+    from bayes_vi_amd.inference.vi import VI
+    from bayes_vi_amd.inference.vi.surrogate_posteriors import ADVI
+    from bayes_vi_amd.model import Model
+    from bayes_vi_amd.utils.datasets import TensorDataset
+    d = r['d']
+    priors = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros(d), 10.), scale=tfd.HalfNormal(10.))
+    model = Model(priors, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
+    lo, hi = rows if rows is not None else (0, r['n'])
+    vi = VI(model, TensorDataset(r['X'][lo:hi], r['y'][lo:hi]), ADVI(model, mean_field=True))
+    return model, vi
+
+
+def _set_surrogate(sur, loc, raw_scale, eps):
+    with torch.no_grad():
+        sur.loc.copy_(loc); sur.raw_scale.copy_(raw_scale)
+    sur.loc.grad = None; sur.raw_scale.grad = None
+    sur.base_noise = lambda n, dim: eps
+
+
+@pytest.mark.parametrize('regime', ['initial', 'converged'])
+def test_elbo_gradient_10m_rows_256_samples(regression_10m, gpu_device, regime):
+    """configs[4] at full size through VI.loss: the mean-field ADVI ELBO and its gradient for 256 samples
+    (vi.py:109-116, surrogate_posteriors.py:113-123) against (i) a float64 evaluation from the sufficient
+    statistics, with the ELBO's chain rule in closed form, and (ii) the sum over two row shards (what the
+    all-reduce of partial log-likelihoods relies on).  'initial': the reference's starting surrogate (loc ~ N(0, 1),
+    unit scale); 'converged': centred on the data-generating parameters with the posterior's own width, where the
+    gradient is a small difference of large sums."""
+    r = regression_10m
+    n, d, S = r['n'], r['d'], 256
+    pu = d + 2
+    g = torch.Generator(device=gpu_device); g.manual_seed(99)
+    eps = torch.randn(S, pu, generator=g, device=gpu_device)
+    if regime == 'initial':
+        loc = torch.randn(pu, generator=g, device=gpu_device)
+        raw = torch.full((pu,), math.log(math.e - 1.0), device=gpu_device)
+    else:
+        beta = torch.linalg.solve(r['A'], r['b'])                                  # least squares, float64
+        s2 = float(r['yy'] - beta @ r['b']) / n
+        loc = torch.cat([beta, torch.tensor([math.log(math.expm1(math.sqrt(s2)))], device=gpu_device,
+                                            dtype=torch.float64)]).float()
+        sd = math.sqrt(s2 / n)
+        raw = torch.full((pu,), math.log(math.expm1(sd)), device=gpu_device)
+    model, vi = _vi_setup(r, gpu_device)
+    sur = vi.surrogate_posterior
+    _set_surrogate(sur, loc, raw, eps)
+    loss = vi.loss(S)
+    loss.backward()
+    # float64 reference: per-sample constrained log-likelihood and gradient from the sufficient statistics
+    sc = torch.nn.functional.softplus(raw.double())
+    z = loc.double() + sc * eps.double()
+    theta = torch.cat([z[:, :d + 1], torch.nn.functional.softplus(z[:, d + 1:])], -1)
+    ll, gth, term = _reference_from_stats(r, theta.float())     # evaluated at the f32 parameters the kernel sees
+    th32 = theta.float().double()
+    lprior = (-0.5 * (th32[:, :d + 1] / 10) ** 2 - 0.5 * math.log(2 * math.pi) - math.log(10)).sum(-1) \
+        + 0.5 * math.log(2 / math.pi) - math.log(10) - 0.5 * (th32[:, d + 1] / 10) ** 2
+    gprior = -th32 / 100.0
+    zs = z[:, d + 1]
+    fldj = -torch.nn.functional.softplus(-zs)
+    logq = (-0.5 * eps.double() ** 2 - 0.5 * math.log(2 * math.pi) - torch.log(sc)).sum(-1) - fldj
+    ref_loss = (logq - ll - lprior).mean()
+    gz = gth + gprior
+    gz[:, d + 1] = gz[:, d + 1] * torch.sigmoid(zs) + torch.sigmoid(-zs)
+    ref_gloc = -gz.mean(0)
+    ref_graw = -((1.0 / sc + gz * eps.double()).mean(0)) * torch.sigmoid(raw.double())
+    # error scale of a gradient entry: that of the per-sample likelihood gradients it averages
+    tz = term.clone(); tz[:, d + 1] = tz[:, d + 1] * torch.sigmoid(zs)
+    gmax = gth.abs().max(-1, keepdim=True).values
+    per_sample = RTOL * (gmax + 3e-2 * tz)
+    tol_loc = per_sample.mean(0)
+    tol_raw = (per_sample * eps.double().abs()).mean(0) * torch.sigmoid(raw.double())
+    assert abs(float(loss.detach()) - float(ref_loss)) <= RTOL * abs(float(ref_loss))
+    assert bool(((sur.loc.grad.double() - ref_gloc).abs() <= tol_loc + RTOL * ref_gloc.abs().max()).all()), \
+        float(((sur.loc.grad.double() - ref_gloc).abs() / (tol_loc + RTOL * ref_gloc.abs().max())).max())
+    assert bool(((sur.raw_scale.grad.double() - ref_graw).abs() <= tol_raw + RTOL * ref_graw.abs().max()).all()), \
+        float(((sur.raw_scale.grad.double() - ref_graw).abs() / (tol_raw + RTOL * ref_graw.abs().max())).max())
+    # row shards: loss and gradient are sums of per-shard parts once the data-free part is counted once
+    full = (loss.detach().double(), sur.loc.grad.double().clone(), sur.raw_scale.grad.double().clone())
+    del vi
+    cut = 6_100_003
+    acc = [torch.zeros((), dtype=torch.float64, device=gpu_device), torch.zeros(pu, dtype=torch.float64, device=gpu_device),
+           torch.zeros(pu, dtype=torch.float64, device=gpu_device)]
+    for rows in ((0, cut), (cut, n)):
+        _, vs = _vi_setup(r, gpu_device, rows)
+        _set_surrogate(vs.surrogate_posterior, loc, raw, eps)
+        ls = vs.loss(S); ls.backward()
+        acc[0] += ls.detach().double(); acc[1] += vs.surrogate_posterior.loc.grad.double()
+        acc[2] += vs.surrogate_posterior.raw_scale.grad.double()
+        del vs
+    # the data-free part (log q - log prior), counted twice above
+    lo_ = loc.clone().requires_grad_(True); ra_ = raw.clone().requires_grad_(True)
+    sc32 = torch.nn.functional.softplus(ra_)
+    z32 = lo_ + sc32 * eps
+    th = torch.cat([z32[:, :d + 1], torch.nn.functional.softplus(z32[:, d + 1:])], -1)
+    lq = (-0.5 * eps ** 2 - 0.5 * math.log(2 * math.pi) - torch.log(sc32)).sum(-1) + torch.nn.functional.softplus(-z32[:, d + 1])
+    lpr = (-0.5 * (th[:, :d + 1] / 10) ** 2 - 0.5 * math.log(2 * math.pi) - math.log(10)).sum(-1) \
+        + 0.5 * math.log(2 / math.pi) - math.log(10) - 0.5 * (th[:, d + 1] / 10) ** 2
+    l0 = (lq - lpr).mean(); l0.backward()
+    assert abs(float(acc[0] - l0.detach().double() - full[0])) <= 2 * RTOL * abs(float(full[0]))
+    assert bool(((acc[1] - lo_.grad.double() - full[1]).abs() <= 2 * (tol_loc + RTOL * ref_gloc.abs().max())).all())
+    assert bool(((acc[2] - ra_.grad.double() - full[2]).abs() <= 2 * (tol_raw + RTOL * ref_graw.abs().max())).all())
+
+
+def test_vi_step_10m_rows_graph_replay_equals_eager(regression_10m, gpu_device):
+    """VI.fit replays the optimisation step as a HIP graph (sampling, fused pass, backward, clipping, Adam): one
+    replayed step from a given state must leave exactly the variables an eagerly executed step leaves."""
+    from bayes_vi_amd.inference.vi.vi import Adam
+    r = regression_10m
+    S, pu = 256, r['d'] + 2
+    g = torch.Generator(device=gpu_device); g.manual_seed(5)
+    eps = torch.randn(S, pu, generator=g, device=gpu_device)
+    loc0 = torch.randn(pu, generator=g, device=gpu_device)
+    raw0 = torch.full((pu,), math.log(math.e - 1.0), device=gpu_device)
+    _, vi = _vi_setup(r, gpu_device)
+    sur = vi.surrogate_posterior
+    params = [p for p in sur.parameters() if p.requires_grad]
+    _set_surrogate(sur, loc0, raw0, eps)
+    sur.loc.grad = torch.zeros_like(sur.loc); sur.raw_scale.grad = torch.zeros_like(sur.raw_scale)
+    opt = Adam(learning_rate=0.01).bind(params)
+    loss_e = vi._step(opt, params, S).clone()
+    eager = [p.detach().clone() for p in params]
+    assert not torch.equal(eager[0], loc0)
+    # record the same step, then replay it from the same state with a fresh optimizer state
+    opt2 = Adam(learning_rate=0.01).bind(params)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = vi._step(opt2, params, S)
+    with torch.no_grad():
+        sur.loc.copy_(loc0); sur.raw_scale.copy_(raw0)
+        opt2.t.zero_()
+        for t in opt2.m + opt2.v:
+            t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_loss, loss_e)
+    for p, e in zip(params, eager):
+        assert torch.equal(p.detach(), e)
