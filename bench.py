@@ -7,15 +7,20 @@ A "step" is one leapfrog step of every chain: momentum half-step, position
 step, ONE fused pass of the hot path over the whole (row-sharded) dataset --
 log-likelihood and gradient for all chains through the C ABI, all-reduced over
 the ranks, plus priors and the bijector chain rule -- and the second momentum
-half-step.  With --gpus N (launched under torch.distributed.run) the rows are
-split over the ranks, chains stay replicated, and every step does one RCCL
-all-reduce of the [chains, 1+P] partial sums: strong scaling of a fixed dataset.
+half-step.  With --gpus N the rows are split over N ranks (one process per GPU),
+chains stay replicated, and every step does one RCCL all-reduce of the
+[chains, 1+P] partial sums: strong scaling of a fixed dataset.  Under
+torch.distributed.run (WORLD_SIZE set) this process is one of the ranks; started
+plainly with --gpus N > 1 it launches torch.distributed.run itself, as a child
+process and before anything here touches a GPU, and relays rank 0's line.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -73,11 +78,57 @@ def cpu_baseline(n_total, d, seconds_budget=12.0):
     }
 
 
+def parity_at_bench_point(X, y, theta, logp, grad, n_chains=64):
+    """Observed error of the timed kernel's own outputs on `n_chains` of the bench's chains, against a float64
+    evaluation from the sufficient statistics of the augmented design [1, X] (accumulated in float64 on the device,
+    outside the timed region): worst |dlogp| / |logp| and worst |dgrad| / max|grad| of the chain."""
+    import math
+    n, d = X.shape
+    dev = X.device
+    A = torch.zeros(d + 1, d + 1, dtype=torch.float64, device=dev)
+    b = torch.zeros(d + 1, dtype=torch.float64, device=dev)
+    yy = torch.zeros((), dtype=torch.float64, device=dev)
+    step = 1 << 20
+    for s in range(0, n, step):
+        Xa = torch.cat([torch.ones(min(step, n - s), 1, dtype=torch.float64, device=dev), X[s:s + step].double()], 1)
+        yc = y[s:s + step].double()
+        A += Xa.T @ Xa; b += Xa.T @ yc; yy += yc @ yc
+    th = theta[:n_chains].double()
+    beta, sc = th[:, :d + 1], th[:, d + 1]
+    s2 = yy - 2 * beta @ b + ((beta @ A) * beta).sum(-1)
+    ref_lp = -0.5 * s2 / sc ** 2 - n * torch.log(sc) - 0.5 * n * math.log(2 * math.pi)
+    ref_g = torch.cat([(b[None] - beta @ A) / sc[:, None] ** 2, (-n / sc + s2 / sc ** 3)[:, None]], -1)
+    e_lp = ((logp[:n_chains].double() - ref_lp).abs() / ref_lp.abs()).max()
+    e_g = ((grad[:n_chains].double() - ref_g).abs().max(-1).values / ref_g.abs().max(-1).values).max()
+    return {'chains_checked': int(n_chains), 'reference': 'float64 sufficient statistics of [1, X] on the device',
+            'max_rel_err_logp': float(e_lp), 'max_err_grad_over_max_abs_grad': float(e_g)}
+
+
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run the same command under torch.distributed.run in a CHILD
+    process (this process has not touched a GPU and never will), relay rank 0's JSON line and the exit code."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{"metric"')]
+    for l in proc.stdout.splitlines():
+        if not l.startswith('{"metric"'):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        raise SystemExit('the ranks exited without a result line')
+    raise SystemExit(proc.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--rows', type=int, default=10_000_000)
     ap.add_argument('--features', type=int, default=64)
     ap.add_argument('--chains', type=int, default=1024)
@@ -89,11 +140,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
-        args.gpus = world
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
+    args.gpus = world
     # BVI_BENCH_REHEARSAL=1: exercise the multi-rank code path on a box with fewer GPUs than ranks (ranks
     # share devices, collectives go through gloo); the numbers of such a run mean nothing
     rehearsal = os.environ.get('BVI_BENCH_REHEARSAL') == '1'
@@ -145,7 +194,7 @@ def main():
     logp, grad = buf[:c], buf[c:].view(c, pc)
     lp = torch.empty(c, dtype=torch.float32, device=device)
     g = torch.empty(c, pu, dtype=torch.float32, device=device)
-    kernel_events = []
+    kernel_events, reduce_events = [], []
 
     def likelihood_pass(timed):
         # HIP events bracket the fused dataset pass on the stream it is launched on (torch's current stream)
@@ -157,6 +206,23 @@ def main():
             e1.record(); kernel_events.append((e0, e1))
         if lik.sharded:
             all_reduce(buf, dist.ReduceOp.SUM)
+            if timed:      # the collective runs on RCCL's stream; the current stream waits for it, so e1 -> e2
+                e2 = torch.cuda.Event(enable_timing=True)      # spans the hand-over, the reduction and the way back
+                e2.record(); reduce_events.append((e1, e2))
+
+    # one-time packing of the dataset for the matrix-core kernel (outside `value`): timed here, on the first use
+    pack_ms = None
+    if lik.matrix_core_format(c) is not None:
+        tiny = LinearRegression(X[:4096], y[:4096], precision=prec)       # loads the pack kernels first
+        tiny.packed = _native.linreg_pack(tiny.X, tiny.y, fmt=lik.matrix_core_format(c))
+        del tiny
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lik.packed = _native.linreg_pack(lik.X, lik.y, fmt=lik.matrix_core_format(c))
+        lik.packed_format = lik.matrix_core_format(c)
+        e1.record(); torch.cuda.synchronize()
+        pack_ms = e0.elapsed_time(e1)
 
     st = _native._stream()
     _native.check(lib.bvi_constrain(blocks, nb, c, ptr(z), ptr(theta), st), 'bvi_constrain')
@@ -215,7 +281,9 @@ def main():
         'metric': 'leapfrog grad-evals/sec (chains x steps) at N=10M, D=64; % of HBM roofline',
         'value': c * args.steps / elapsed,
         'unit': 'grad-evals/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world, 'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
+        'collective_backend': (dist.get_backend() if dist.is_initialized() else None),
+        'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True,
         'scaling': 'strong',
@@ -235,7 +303,15 @@ def main():
                     'peak_GBps': HBM_PEAK_GBPS, 'frac': alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         },
         'finite': finite,
+        'allreduce_ms': (sum(a.elapsed_time(b) for a, b in reduce_events) / len(reduce_events)) if reduce_events else None,
+        'pack_ms': pack_ms,
     }
+    if rank == 0 and world == 1:
+        # what the timed kernel returned at the bench's own operating point, against float64
+        th_chk = theta.clone()
+        lik._call(th_chk, logp, grad)
+        torch.cuda.synchronize()
+        out['parity_at_bench_point'] = parity_at_bench_point(X, y, th_chk, logp, grad, min(64, c))
     if rank == 0 and world == 1 and d <= 64:
         # the HBM-bound regime of the same path: 16 chains on the same dataset (reported next to the headline
         # because the metric asks for a fraction of the HBM roof, which only binds at few chains).  `achieved` is
@@ -261,7 +337,14 @@ def main():
                        else 'linreg_f32_kernel + linreg_finalize'),
             'bound': 'hbm', 'ms': ms16,
             'achieved': b16 / (ms16 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'achieved_is': 'algorithmic bytes of the f32 dataset, 4 N (D+1), over the time',
             'frac': b16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'grad_evals_per_s': c16 / (ms16 * 1e-3)}
+        if fmt16 == _native.PACK_F16:
+            # the kernel itself streams the packed f16 plane + y: these are the bytes DRAM actually delivers
+            dram = 2.0 * n_local * (32 if d <= 32 else 64) + 4.0 * n_local
+            out['roofline_hbm_regime']['dram_bytes_per_launch'] = dram
+            out['roofline_hbm_regime']['dram_GBps'] = dram / (ms16 * 1e-3) / 1e9
+            out['roofline_hbm_regime']['dram_frac'] = dram / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(n, d)
     if rank == 0:
