@@ -18,7 +18,9 @@ PACK_BF16X3, PACK_F16 = 0, 1
 BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED, BIJ_FILL_SCALE_TRIL = 0, 1, 2, 3, 4
 PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
-ABI_VERSION = 101     # BVI_VERSION of include/bvi.h this binding was written against
+NOALLOC_MAX_CHAINS = 256
+ERR_TOO_LARGE = -4
+ABI_VERSION = 102     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -71,6 +73,8 @@ def lib():
         l.bvi_workspace_bytes.argtypes = [i32, i64, i32, i32, i32, ctypes.POINTER(sz)]
         l.bvi_normal_iid_logp_grad.argtypes = [vp, i64, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
+        l.bvi_normal_iid_logp_grad_noalloc.argtypes = [vp, i64, vp, i32, vp, vp, vp]
+        l.bvi_normal_iid_logp_grad_noalloc.restype = i32
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, sz, vp]
         l.bvi_linreg_packed_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]

@@ -12,6 +12,8 @@ const char* bvi_status_string(int status) {
     case BVI_ERR_ARG: return "invalid argument (null pointer, negative size, misaligned X or bad enum)";
     case BVI_ERR_UNSUPPORTED: return "shape or precision not supported by the gfx950 kernels";
     case BVI_ERR_WORKSPACE: return "workspace missing or smaller than bvi_workspace_bytes()";
+    case BVI_ERR_TOO_LARGE:
+      return "size beyond the fixed device scratch of the allocation-free entry point (at most 256 chains)";
     default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown status";
   }
 }

@@ -16,6 +16,7 @@
 // reduced over the 4 waves through LDS, and written as one partial per
 // workgroup; finalize adds the partials in fixed order in double.
 #include "bvi_common.h"
+#include <mutex>
 
 template <int CP>
 __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict__ y, int64_t n,
@@ -206,4 +207,46 @@ int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, 
                        n, theta, c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
+}
+
+// ---- the allocation-free variant: scratch in a file-scope device array instead of a caller workspace ----
+// For callers that cannot allocate device memory (code under HIP graph capture, tight serving loops).  The
+// per-row-block partial sums of the kernels above go to `scratch`; every launch writes each partial it later
+// reads (all row blocks x all chains of the call), so nothing has to be cleared between calls.  All calls on one
+// GPU share that GPU's array: calls that overlap in time on one GPU race.
+static __device__ __align__(256) float scratch[(size_t)BVI_MAX_ROW_BLOCKS * BVI_NOALLOC_MAX_CHAINS * 2];
+
+#define BVI_MAX_DEVICES 64
+static float* scratch_ptr[BVI_MAX_DEVICES];   // device address of `scratch` on each GPU, looked up once per device
+static std::mutex scratch_lock;
+
+// The array's name is only a host-side handle; the kernels need the address hipGetSymbolAddress reports for the
+// current device (each GPU holds its own copy at its own address).
+static int noalloc_scratch(float** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= BVI_MAX_DEVICES) return BVI_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> guard(scratch_lock);
+  if (!scratch_ptr[dev]) {
+    float* ptr = nullptr;
+    e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!ptr) return BVI_ERR_ARG;
+    scratch_ptr[dev] = ptr;
+  }
+  *out = scratch_ptr[dev];
+  return BVI_OK;
+}
+
+extern "C" int bvi_normal_iid_logp_grad_noalloc(const float* y, int64_t n, const float* theta, int n_chains,
+                                                float* logp, float* grad, void* stream) {
+  if ((!y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (n_chains > BVI_NOALLOC_MAX_CHAINS) return BVI_ERR_TOO_LARGE;
+  if (bvi_ws_normal_iid(n, n_chains) > sizeof(float) * (size_t)BVI_MAX_ROW_BLOCKS * BVI_NOALLOC_MAX_CHAINS * 2)
+    return BVI_ERR_TOO_LARGE;
+  float* ws = nullptr;
+  const int st = noalloc_scratch(&ws);
+  if (st != BVI_OK) return st;
+  return bvi_launch_normal_iid(y, n, theta, n_chains, logp, grad, ws, (hipStream_t)stream);
 }

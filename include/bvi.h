@@ -42,12 +42,13 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 101
+#define BVI_VERSION 102
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
 #define BVI_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels cover         */
 #define BVI_ERR_WORKSPACE (-3)    /* ws is NULL or smaller than bvi_workspace_bytes */
+#define BVI_ERR_TOO_LARGE (-4)    /* beyond the fixed scratch of an allocation-free entry point */
 
 /* likelihood families */
 #define BVI_FAMILY_NORMAL_IID 0   /* tfd.Sample(tfd.Normal(loc, scale), N)              README.md:114-120 */
@@ -109,6 +110,18 @@ int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, 
  * taken by tfp.mcmc kernels (transition_kernels.py:122-128, 238-246). */
 int bvi_normal_iid_logp_grad(const float* y, int64_t n, const float* theta, int n_chains,
                              float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+
+/* The same computation as bvi_normal_iid_logp_grad WITHOUT a workspace argument and without any allocation:
+ * the per-row-block partial sums live in a device array inside the library (2 MiB, held on every GPU the library
+ * has run on until the process ends).  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * At most BVI_NOALLOC_MAX_CHAINS chains (any n); more returns BVI_ERR_TOO_LARGE.  Results are identical to
+ * bvi_normal_iid_logp_grad's.  All calls on one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (different streams or threads) race; calls on one stream, or on different GPUs, do not.  The first call on
+ * each GPU looks the array's address up (hipGetSymbolAddress): make it outside graph capture. */
+#define BVI_NOALLOC_MAX_CHAINS 256
+int bvi_normal_iid_logp_grad_noalloc(const float* y, int64_t n, const float* theta, int n_chains,
+                                     float* logp, float* grad, void* stream);
 
 /* Gaussian linear regression: X[n,d] row-major, y[n],
  * theta[C,d+2] = (beta_0, w_1..w_d, scale) -> logp[C], grad[C,d+2].
