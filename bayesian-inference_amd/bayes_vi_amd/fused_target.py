@@ -138,6 +138,11 @@ class LinearRegression(FusedLogLikelihood):
         if self.X.dim() == 1:
             self.X = self.X[:, None]
         self.y = y.to(torch.float32).contiguous().reshape(-1)
+        # the kernels read 16-byte vectors: a row slice of a larger tensor (a shard) may start between them
+        if self.X.data_ptr() % 16:
+            self.X = self.X.clone()
+        if self.y.data_ptr() % 16:
+            self.y = self.y.clone()
         self.n, self.d = self.X.shape
         self.n_params = self.d + 2
         self.precision = precision

@@ -1,9 +1,12 @@
 """`MCMC`: posterior sampling (mirror of bayes_vi/inference/mcmc/mcmc.py)."""
 import collections
+import os
 
 import torch
+import torch.distributed as dist
 
 from ...fused_target import replicate_from_rank0
+from ...utils import compose
 from ..inference import Inference
 from .sample_results import SampleResult
 from .samplers import sample_chain
@@ -54,19 +57,23 @@ class MCMC(Inference):
         """Returns a `SampleResult`: samples as a list of [num_samples, num_chains, *event] per
         parameter (or one merged [num_samples, num_chains, P] entry with merge_state_parts) and the
         kernel's traced metrics (mcmc.py:101-185)."""
-        gen = None
-        if seed is not None:
-            gen = torch.Generator(device='cpu'); gen.manual_seed(int(seed))
+        # One seed drives everything random in the run: the initial state, the counter-based device streams and
+        # the generators of the host kernels.  Without `seed` a fresh one is drawn, so that repeated fits are
+        # independent runs (as the reference's are); with rows sharded over ranks it is rank 0's, so that the
+        # replicated chains see the same momenta and accept draws on every rank whatever kernel is selected.
+        if seed is None:
+            seed = int.from_bytes(os.urandom(7), 'little')
+        wire = torch.tensor([int(seed)], dtype=torch.int64)
+        if self.group is not None and dist.is_initialized() and dist.get_backend(self.group) != 'gloo':
+            wire = wire.to(self.device)
+        seed = int(replicate_from_rank0(wire, self.group)[0])
+        gen = torch.Generator(device='cpu'); gen.manual_seed(seed)
         z0 = self._process_initial_state(initial_state, num_chains, generator=gen)
-        # rows sharded over ranks: the chains are replicated, so all ranks start where rank 0 starts (pass `seed`
-        # as well when a kernel draws from torch's generators rather than from the counter-based device streams)
         z0 = replicate_from_rank0(z0.contiguous(), self.group)
-        dgen = None
-        if seed is not None:
-            dgen = torch.Generator(device=self.device); dgen.manual_seed(int(seed) + 1)
+        dgen = torch.Generator(device=self.device); dgen.manual_seed((seed + 1) % (1 << 63))
 
         target = self.posterior.unconstrained_log_prob_and_grad
-        kernel, trace_metrics = self.transition_kernel(target)
+        kernel, trace_fns, trace_metrics = self.transition_kernel(target)
 
         progress = None
         if progress_bar:
@@ -76,7 +83,8 @@ class MCMC(Inference):
                 progress = lambda i, n: bar.update(i - bar.n)
             except Exception:
                 progress = None
-        zs, traces = sample_chain(kernel, z0, num_samples, num_burnin_steps, generator=dgen, progress=progress)
+        zs, trace = sample_chain(kernel, z0, num_samples, num_burnin_steps, generator=dgen, progress=progress,
+                                 trace_fn=compose(list(reversed(trace_fns))))
         if progress_bar and progress is not None:
             bar.close()
 
@@ -84,5 +92,5 @@ class MCMC(Inference):
         samples = [theta] if merge_state_parts else self.model.split_state(theta)
         if merge_state_parts:
             samples = self.model.split_state(theta)   # the reference un-merges before returning (mcmc.py:176-179)
-        trace_dict = {name: traces[name] for name in trace_metrics}
+        trace_dict = {name: values for name, values in zip(trace_metrics, trace)}
         return SampleResult(samples, trace_dict)

@@ -333,9 +333,36 @@ class DualAveragingStepSizeAdaptation:
         return z, state, trace
 
 
-def sample_chain(kernel, z0, num_results, num_burnin_steps, generator=None, progress=None):
+class KernelResults(dict):
+    """What a kernel reports about its transitions (tfp's "kernel results"): fields by name, also readable as
+    attributes; a wrapping kernel's results hold the wrapped kernel's under `inner_results`, which is what the
+    reference's unwrapping trace functions walk down (transition_kernels.py:30, 37; mcmc.py:157)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+
+def kernel_results(kernel, traces):
+    """The results of `kernel` for the transitions whose traced fields `traces` holds, nested the way the kernel
+    objects are nested (step-size adaptation around the sampling kernel)."""
+    if hasattr(kernel, 'inner'):
+        return KernelResults(inner_results=kernel_results(kernel.inner, traces),
+                             new_step_size=getattr(kernel.inner, 'step_size', None))
+    return KernelResults(traces)
+
+
+def sample_chain(kernel, z0, num_results, num_burnin_steps, generator=None, progress=None, trace_fn=None):
     """tfp.mcmc.sample_chain restated: burn in, then collect `num_results` states and the
-    kernel's traced quantities.  Returns (samples[num_results, C, P], {name: [num_results, ...]})."""
+    kernel's traced quantities.  Returns (samples[num_results, C, P], {name: [num_results, ...]}); with
+    `trace_fn(states, kernel_results)` (mcmc.py:167-173) the second entry is what it returns for the collected
+    transitions (every field stacked over them)."""
+    if trace_fn is not None:
+        samples, traces = sample_chain(kernel, z0, num_results, num_burnin_steps, generator=generator,
+                                       progress=progress)
+        return samples, trace_fn(samples, kernel_results(kernel, traces))
     z = z0
     state = kernel.bootstrap(z)
     if not bool(torch.isfinite(state['target_log_prob']).all()):

@@ -1,21 +1,23 @@
-"""Utility functions and classes (mirror of bayes_vi/utils/__init__.py:16-30)."""
-import collections
-import functools
+"""Utility functions and classes (the names of bayes_vi/utils/__init__.py:16-30)."""
+from collections import OrderedDict
+from functools import reduce
 
 __all__ = ['datasets', 'symplectic_integrators', 'compose', 'to_ordered_dict']
 
 
 def compose(fns):
-    """Left-to-right composition: the result tuple of each function is splatted into the next
-    (how the reference chains its trace functions, bayes_vi/utils/__init__.py:16-25)."""
-    def composition(*args, fns_):
-        res = fns_[0](*args)
-        for f in fns_[1:]:
-            res = f(*res)
-        return res
-    return functools.partial(composition, fns_=fns)
+    """One callable that feeds its arguments to fns[0] and then unpacks each result tuple into the next function
+    of the list; the last function's result is returned.  `MCMC.fit` chains the trace functions of nested kernels
+    with it, outermost first (bayes_vi/inference/mcmc/mcmc.py:172)."""
+    steps = tuple(fns)
+    if not steps:
+        raise ValueError('compose needs at least one function')
+
+    def composed(*args):
+        return reduce(lambda result, fn: fn(*result), steps[1:], steps[0](*args))
+    return composed
 
 
 def to_ordered_dict(param_names, state):
-    """List of state parts -> OrderedDict keyed by parameter name (utils/__init__.py:28-30)."""
-    return collections.OrderedDict([(k, v) for k, v in zip(param_names, state)])
+    """Pairs parameter names with the state parts given in the same order."""
+    return OrderedDict(zip(param_names, state))

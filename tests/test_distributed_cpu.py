@@ -100,6 +100,51 @@ def test_row_sharded_posterior_world2(tmp_path):
     np.testing.assert_allclose(res['zs'].numpy(), zs.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def _fit_worker(rank, world, port, out):
+    """MCMC.fit without a seed on a row-sharded posterior whose kernel draws from torch generators (a host kernel):
+    every rank has its own global RNG state, and the chains must still be identical on all ranks."""
+    import collections
+    from bayes_vi_amd.inference.mcmc import MCMC
+    from bayes_vi_amd.inference.mcmc.transition_kernels import HamiltonianMonteCarlo
+    from bayes_vi_amd.model import Model
+    from bayes_vi_amd import symbolic
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)
+    X, y, _ = make_data()
+    shard = TensorDataset(X, y).shard(rank, world)
+    priors = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros(D), 10.), scale=tfd.HalfNormal(10.))
+    model = Model(priors, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
+    mcmc = MCMC.__new__(MCMC)                      # the driver object around the oracle-backed shard likelihood
+    mcmc.model, mcmc.dataset = model, shard
+    mcmc.posterior = make_posterior(shard.features, shard.targets, dist.group.WORLD)
+    mcmc.device, mcmc.group = torch.device('cpu'), dist.group.WORLD
+    mcmc.transition_kernel = HamiltonianMonteCarlo(step_size=0.005, num_leapfrog_steps=3)
+    res = mcmc.fit(num_chains=3, num_samples=6, num_burnin_steps=2, progress_bar=False)
+    flat = torch.cat([s.reshape(6, 3, -1) for s in res.samples], -1)
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(gathered[0], t) for t in gathered)
+    acc = res.trace['is_accepted'].to(torch.float32)
+    both = [torch.empty_like(acc) for _ in range(world)]
+    dist.all_gather(both, acc)
+    assert all(torch.equal(both[0], t) for t in both)
+    if rank == 0:
+        torch.save(dict(flat=flat), out)
+    dist.destroy_process_group()
+
+
+def test_unseeded_fit_keeps_row_sharded_chains_replicated(tmp_path):
+    outs = []
+    for i in range(2):                 # two unseeded runs are different runs
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        out = str(tmp_path / ('fit%d.pt' % i))
+        mp.spawn(_fit_worker, args=(2, port, out), nprocs=2, join=True)
+        outs.append(torch.load(out)['flat'])
+    assert torch.isfinite(outs[0]).all()
+    assert not torch.equal(outs[0], outs[1])
+
+
 def test_shard_covers_all_rows_once():
     ds = TensorDataset({'a': torch.arange(10.)}, torch.arange(10.))
     for world in (1, 2, 3, 4, 7, 8):

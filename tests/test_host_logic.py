@@ -239,15 +239,22 @@ def test_posterior_moments_match_reference_table(kernel_name):
     else:
         cfg = RandomWalkMetropolis(new_state_fn=lambda z, g: z + 0.15 * torch.randn(z.shape, generator=g, dtype=z.dtype))
         burn, draws = 1000, 6000
-    kernel, names = cfg(target)
-    zs, tr = samplers.sample_chain(kernel, z0, draws, burn, generator=gen)
+    # the reference's contract (transition_kernels.py:24-38, consumed at mcmc.py:150, 172)
+    kernel, trace_fns, names = cfg(target)
+    assert names == cfg.trace_fn_metrics and all(callable(f) for f in trace_fns)
+    assert len(trace_fns) == (2 if kernel_name != 'rwm' else 1)       # own trace_fn + one unwrap per wrapping kernel
+    from bayes_vi_amd.utils import compose
+    zs, trace = samplers.sample_chain(kernel, z0, draws, burn, generator=gen,
+                                      trace_fn=compose(list(reversed(trace_fns))))
+    assert isinstance(trace, tuple) and len(trace) == len(names)
+    tr = dict(zip(names, trace))
+    assert all(v.shape[0] == draws for v in trace)
     th = spec.constrain(zs.reshape(-1, 2).numpy())
     tol = 0.03 if kernel_name != 'rwm' else 0.05
     assert th[:, 0].mean() == pytest.approx(3.37, abs=tol)
     assert th[:, 0].std() == pytest.approx(0.16, abs=0.02)
     assert th[:, 1].mean() == pytest.approx(1.68, abs=tol)
     assert th[:, 1].std() == pytest.approx(0.12, abs=0.02)
-    assert set(names) <= set(tr.keys())
     acc = tr['is_accepted'].to(torch.float32).mean()
     assert 0.15 < float(acc) <= 1.0
     if kernel_name == 'nuts':
