@@ -358,3 +358,69 @@ class _TargetLogProbFn(torch.autograd.Function):
 def differentiable_log_prob(posterior: Posterior, theta):
     """Constrained log pi(theta) for theta[S, P], differentiable by torch autograd."""
     return _TargetLogProbFn.apply(theta, posterior)
+
+
+class PotentialEnergy:
+    """U(q) = -log pi(q) in unconstrained coordinates as an energy function for
+    `LeapfrogIntegrator.solve` (bayes_vi/utils/symplectic_integrators.py:12-59): calling it gives the energy
+    [C] (differentiable by autograd through the fused node), `.grad(q)` its gradient from the fused pass without
+    autograd.  Together with `QuadraticKineticEnergy` the integrator runs its steps on the device-resident
+    leapfrog entry points (`leapfrog_on_device`)."""
+
+    def __init__(self, posterior: Posterior):
+        self.posterior = posterior
+
+    def __call__(self, q):
+        bij = self.posterior.bijector
+        return -(differentiable_log_prob(self.posterior, bij.forward(q).contiguous())
+                 + bij.forward_log_det_jacobian(q))
+
+    def grad(self, q):
+        return -self.posterior.unconstrained_log_prob_and_grad(q.detach().contiguous())[1]
+
+
+class QuadraticKineticEnergy:
+    """T(p) = |p|^2 / 2, the kinetic energy of HMC with unit mass."""
+
+    def __call__(self, p):
+        return 0.5 * (p * p).sum(-1)
+
+    def grad(self, p):
+        return p
+
+
+def leapfrog_on_device(posterior: Posterior, state, step_size: float, n_steps: int):
+    """n leapfrog steps of H(q, p) = -log pi(q) + |p|^2 / 2 on state[C, 2 Pu] = [q | p] with q, p and the
+    gradient resident on the device: bvi_constrain + data pass + bvi_posterior_assemble for the gradient at the
+    start, then per step bvi_leapfrog_pre -> fused data pass (+ all-reduce over row shards) -> bvi_leapfrog_mid
+    (bvi_leapfrog_post after the last step).  The same update order as symplectic_integrators.py:45-56 with the
+    half steps of neighbouring iterations merged.  Not differentiable; returns a new [C, 2 Pu] tensor."""
+    blocks = posterior.device_blocks()
+    if blocks is None:
+        raise _native.BviError('the device leapfrog needs built-in priors and bijectors')
+    lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
+    pu, pc = posterior.n_unconstrained, posterior.n_constrained
+    c = state.shape[0]
+    z = state[:, :pu].detach().clone().contiguous()
+    p = state[:, pu:].detach().clone().contiguous()
+    if n_steps <= 0:
+        return torch.cat([z, p], -1)
+    nb = len(blocks)
+    theta = torch.empty(c, pc, dtype=torch.float32, device=z.device)
+    lp = torch.empty(c, dtype=torch.float32, device=z.device)
+    g = torch.empty_like(z)
+    _native.check(lib.bvi_constrain(blocks, nb, c, ptr(z), ptr(theta), st), 'bvi_constrain')
+    ll, gl = posterior.likelihood.logp_grad(theta, True)
+    _native.check(lib.bvi_posterior_assemble(blocks, nb, c, ptr(z), ptr(theta), ptr(ll), ptr(gl), ptr(lp), ptr(g), st),
+                  'bvi_posterior_assemble')
+    eps = float(step_size)
+    _native.check(lib.bvi_leapfrog_pre(blocks, nb, c, eps, ptr(z), ptr(p), ptr(g), ptr(theta), st), 'bvi_leapfrog_pre')
+    for k in range(n_steps):
+        ll, gl = posterior.likelihood.logp_grad(theta, True)
+        if k != n_steps - 1:
+            _native.check(lib.bvi_leapfrog_mid(blocks, nb, c, eps, ptr(z), ptr(p), ptr(theta), ptr(ll), ptr(gl),
+                                               ptr(lp), ptr(g), st), 'bvi_leapfrog_mid')
+        else:
+            _native.check(lib.bvi_leapfrog_post(blocks, nb, c, eps, ptr(z), ptr(p), ptr(theta), ptr(ll), ptr(gl),
+                                                ptr(lp), ptr(g), st), 'bvi_leapfrog_post')
+    return torch.cat([z, p], -1)

@@ -769,3 +769,101 @@ def test_fullcov_device_assembly_and_hmc_step_wide_parameter_vectors(bvi, gpu_de
     np.testing.assert_array_equal(tr['is_accepted'].cpu().numpy()[safe], acc_ref[safe])
     np.testing.assert_allclose(z1.cpu().numpy()[safe], q_ref[safe], rtol=5e-5, atol=5e-5)
     np.testing.assert_allclose(tr['log_accept_ratio'].cpu().numpy(), lr_ref, atol=2e-2 + 1e-6 * np.abs(rlp).max())
+
+
+# ---- LeapfrogIntegrator.solve and HamiltonianFlow on the device (symplectic_integrators.py:12-59,
+# ---- flow_bijectors.py:67-81)
+def test_leapfrog_solve_on_device_orbit_and_step_size_forms(gpu_device):
+    from bayes_vi_amd.utils.symplectic_integrators import LeapfrogIntegrator
+    from oracle import leapfrog as lf
+    integ = LeapfrogIntegrator()
+    U = lambda q: 0.5 * (q * q).sum(-1)
+    T = lambda p: 0.5 * (p * p).sum(-1)
+    # README.md:571-591: harmonic oscillator, step 0.5, from (1, 0): 20 applications of one step
+    x = torch.tensor([[1.0, 0.0]], device=gpu_device)
+    orbit = []
+    for _ in range(20):
+        x = integ.solve(U, T, x, torch.tensor(0.5, device=gpu_device), 1)
+        orbit.append(x.cpu().numpy()[0])
+    np.testing.assert_allclose(orbit[0], [0.875, -0.46875], rtol=1e-7)
+    np.testing.assert_allclose(orbit[-1], [-0.7760410416, 0.6106556172], rtol=2e-5)
+    inv = [q * q + p * p / (1 - 0.25 * 0.25) for q, p in orbit]
+    np.testing.assert_allclose(inv, 1.0, rtol=1e-5)
+    # per-dimension, negative and trainable step sizes against the fp64 restatement
+    rng = np.random.default_rng(0)
+    d = 5
+    A = rng.normal(size=(d, d)); A = A @ A.T / d + np.eye(d)
+    At = torch.tensor(A, dtype=torch.float32, device=gpu_device)
+    Uq = lambda q: 0.5 * ((q @ At) * q).sum(-1) + 0.1 * (q ** 4).sum(-1)
+    gU = lambda q: q @ A + 0.4 * q ** 3
+    x0 = rng.normal(size=(7, 2 * d)).astype(np.float32)
+    for eps in (np.float32(0.07), -np.linspace(0.02, 0.1, d).astype(np.float32)):
+        e = torch.nn.Parameter(torch.tensor(eps, device=gpu_device))
+        out = integ.solve(Uq, T, torch.tensor(x0, device=gpu_device), e, 4)
+        ref = lf.solve(gU, lambda p: p, x0, eps, 4)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+        out.sum().backward()
+        assert e.grad is not None and bool(torch.isfinite(e.grad).all())
+    with pytest.raises(ValueError):
+        integ.solve(Uq, T, torch.zeros(3, 5, device=gpu_device), 0.1, 1)
+
+
+def test_hamiltonian_flow_is_volume_preserving_and_invertible_on_device(bvi, gpu_device):
+    torch.manual_seed(0)
+    d = 6
+    flow = bvi.HamiltonianFlow(d, step_sizes=torch.nn.Parameter(torch.tensor(0.1)), num_integration_steps=3,
+                               hidden_layers=[32, 32]).to(gpu_device)
+    x = torch.randn(16, 2 * d, device=gpu_device)
+    y = flow.forward(x)
+    assert tuple(y.shape) == (16, 2 * d) and float((y - x).detach().abs().max()) > 1e-3
+    back = flow.inverse(y)
+    np.testing.assert_allclose(back.detach().cpu().numpy(), x.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    assert float(flow.forward_log_det_jacobian(x).abs().max()) == 0.0
+    assert float(flow.inverse_log_det_jacobian(y).abs().max()) == 0.0
+    # the declared log-det-Jacobian of 0 is the true one: the Jacobian of the flow map has determinant 1
+    J = torch.autograd.functional.jacobian(lambda v: flow.forward(v[None])[0], x[0].double().float())
+    assert float(torch.linalg.det(J.double())) == pytest.approx(1.0, abs=2e-4)
+
+
+def test_leapfrog_solve_fast_path_on_the_model_posterior(bvi, gpu_device):
+    """`solve` with U = -log posterior and T = |p|^2/2 runs on the device leapfrog kernels around the fused pass;
+    same result as the generic route (closed-form gradient hook, torch updates) and as the fp64 restatement."""
+    from bayes_vi_amd.fused_target import PotentialEnergy, QuadraticKineticEnergy
+    from bayes_vi_amd.utils.symplectic_integrators import LeapfrogIntegrator
+    from oracle import leapfrog as lf
+    rng = np.random.default_rng(5)
+    n, d, c = 4000, 12, 9
+    X = rng.normal(size=(n, d)).astype(np.float32); w = rng.normal(size=d)
+    y = (0.5 + X @ w + rng.normal(size=n)).astype(np.float32)
+    priors = collections.OrderedDict(b=bvi.tfd.Normal(0., 10.), w=bvi.tfd.Normal(torch.zeros(d), 10.),
+                                     scale=bvi.tfd.HalfNormal(10.))
+    model = bvi.Model(priors, lambda b, w, scale, features: bvi.tfd.Normal(
+        loc=b + bvi.symbolic.matvec(features, w), scale=scale))
+    df = pd.DataFrame(X, columns=['f%d' % i for i in range(d)]); df['y'] = y
+    ds = bvi.make_dataset_from_df(df, ['y'], ['f%d' % i for i in range(d)], format_features_as='tensor')
+    post = bvi.MCMC(model, ds).posterior
+    spec = cf.linreg_model(X, y)
+    pu = d + 2
+    z0 = np.concatenate([0.5 + 0.05 * rng.normal(size=(c, 1)), w + 0.05 * rng.normal(size=(c, d)),
+                         0.5 + 0.05 * rng.normal(size=(c, 1))], -1)
+    x0 = np.concatenate([z0, rng.normal(size=(c, pu))], -1).astype(np.float32)
+    U, T = PotentialEnergy(post), QuadraticKineticEnergy()
+    integ = LeapfrogIntegrator()
+    xt = torch.tensor(x0, device=gpu_device)
+    eps, steps = 2e-3, 5
+    assert integ._device_route(U, T, xt, eps) is not None
+    fast = integ.solve(U, T, xt, eps, steps)
+    assert integ._device_route(U, T, xt, torch.full((pu,), eps, device=gpu_device)) is None
+    generic = integ.solve(U, T, xt, torch.full((pu,), eps, device=gpu_device), steps)
+    ref = lf.solve(lambda q: -spec.log_post_unconstrained(q)[1], lambda p: p, x0, eps, steps)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(fast.cpu().numpy(), ref, rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(generic.cpu().numpy(), ref, rtol=0, atol=2e-5 * scale)
+    assert torch.equal(xt, torch.tensor(x0, device=gpu_device))          # the input state is not modified
+    # the energy itself, and its autograd gradient through the fused node
+    q = xt[:, :pu].clone().requires_grad_(True)
+    e = U(q)
+    rlp, rg = spec.log_post_unconstrained(x0[:, :pu])
+    assert_logp_close(-e.detach().cpu().numpy(), rlp)
+    e.sum().backward()
+    assert_grad_close(-q.grad.cpu().numpy(), rg)
