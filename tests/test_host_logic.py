@@ -261,6 +261,31 @@ def test_posterior_moments_match_reference_table(kernel_name):
         assert int(tr['leapfrogs_taken'].max()) <= 31 and not bool(tr['has_divergence'].any())
 
 
+def test_linreg_nuts_matches_reference_table():
+    """linear_regression_experiment dataset 7 (dataset_infos.txt:12, mcmc_summary_statistics.txt:24-26): the
+    reference's NUTS + dual averaging summary beta0 -8.12 +- 0.87, beta1 3.61 +- 0.09, scale 8.66 +- 0.63,
+    sampled here by this repository's NUTS on the oracle's posterior of data standardised to the printed sample
+    statistics (x itself was not saved: beta0 and the spreads carry that looseness)."""
+    from test_oracle_pins import LINREG_TABLE, linreg_table_dataset
+    (b0, b1, s), (m0, s0), (m1, s1), (ms, ss) = LINREG_TABLE[7]
+    x, y = linreg_table_dataset(b0, b1, s)
+    spec = cf.linreg_model(x[:, None], y)
+    cfg = NoUTurnSampler(stepsize_adaptation_kernel=DualAveragingStepSizeAdaptation(num_adaptation_steps=400))
+    kernel, trace_fns, names = cfg(oracle_target(spec))
+    rng = np.random.default_rng(4)
+    c = 4
+    z0 = torch.tensor(spec.unconstrain(np.array([[b0, b1, s]] * c)) + rng.uniform(-.2, .2, (c, 3)))
+    zs, tr = samplers.sample_chain(kernel, z0, 1500, 500, generator=torch.Generator().manual_seed(3))
+    th = spec.constrain(zs.reshape(-1, 3).numpy())
+    assert th[:, 1].mean() == pytest.approx(m1, abs=0.015)
+    assert th[:, 2].mean() == pytest.approx(ms, abs=0.08)
+    assert th[:, 2].std() == pytest.approx(ss, abs=0.06)
+    assert th[:, 0].mean() == pytest.approx(m0, abs=0.15)
+    assert th[:, 0].std() == pytest.approx(s0, rel=0.12)
+    assert th[:, 1].std() == pytest.approx(s1, rel=0.3)
+    assert not bool(tr['has_divergence'].any())
+
+
 def test_recognise_fullcov_mixture_and_batched_tril():
     k, d = 3, 2
     m = d * (d + 1) // 2
