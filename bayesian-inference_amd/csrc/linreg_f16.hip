@@ -24,22 +24,20 @@
 // Same likelihood node as there: tfd.Normal(beta_0 + X w, scale)
 // (bayes_vi/model/model.py:194-203, README.md:754-756).
 //
-// f16 has 11 significant bits but only 5 exponent bits, so every f16 operand is brought to the top
-// of its range by an exact power-of-two scale:
-//   x'_id = x_id * s_d,    s_d = 2^(13 - floor(log2 max_i |x_id|))            (per column, at pack time;
+// f16 has 11 significant bits but only 5 exponent bits, so every f16 operand is brought into its range by an
+// exact power-of-two scale:
+//   x'_id = x_id * s_d,    s_d = 2^(4 - floor(log2 max_i |x_id|))              (per column, at pack time;
 //                                                                          0 for an all-zero column)
-//   w''_cd = -w_cd / s_d * t_c,  t_c = 2^(13 - floor(log2 max_d |w_cd / s_d|))  (per chain, per call)
-// so that |x'|, |w''| < 2^14 and z' = sum_d x'_id w''_cd = -t_c x_i.w_c accumulates in f32; the low
-// piece of the residuals then sits 2^-11 below its high piece, far above the f16 subnormal threshold for every
-// element that matters to the sum.  The residuals are produced already scaled for the gradient GEMM,
-//   r'_ic = u r_ic = z'_ic (u / t_c) + (u y_i - u b0_c),
-//   u = min over the workgroup's chains of 2^(14 - floor(log2 (max|y| + |b0_c| + D 2^14 max_d |w_cd / s_d|)))
-// : the bound holds for every row, so |r'| < 2^15, and it is loose by a few binades only, which
-// leaves ~20 binades of f16 range below a typical residual.  u is one number per workgroup so that
-// u y_i is formed once, when a tile is staged, and not per chain.  S2' = sum r'^2 and
-// G'_cd = sum_i r'_ic x'_id are rescaled by 1 / u^2 and 1 / (u s_d) in the finalize kernel (exact:
-// powers of two).  S1 = sum_i r_i is not accumulated at all: it equals sum y - n b0 - w . (column
-// sums of X), with the data sums taken once, in double, at pack time.
+//   w''_cd = -w_cd / s_d * t_c                                              (per chain, per call)
+//   t_c = 2^(14 - floor(log2 (max|y| + |b0_c| + D 2^5 max_d |w_cd / s_d|)))
+// The bracket bounds |r_ic| for every row.  With the accumulator of the residual GEMM started at -t_c b0_c (a
+// register constant) one fma per residual adds t_c y_i and gives the scaled residuals themselves,
+//   r'_ic = t_c r_ic = t_c y_i + (-t_c b0_c + sum_d x'_id w''_cd),         |r'| < 2^15,
+// with |w''| <= 2^10 / D * 64; the bound is loose by a few binades only, which leaves ~20 binades of f16 range
+// below a typical residual, and the low piece of the residuals sits 2^-11 below its high piece.  S2' = sum r'^2
+// and G'_cd = sum_i r'_ic x'_id are rescaled by 1 / t_c^2 and 1 / (t_c s_d) in the finalize kernel (exact: powers
+// of two), which recomputes t_c with the same arithmetic.  S1 = sum_i r_i is not accumulated at all: it equals
+// sum y - n b0 - w . (column sums of X), with the data sums taken once, in double, at pack time.
 //
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
 //   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
@@ -58,13 +56,14 @@
 // takes the same row order from two transposed LDS reads (ds_read_b64_tr_b16).
 //
 // The loop is bound by vector-instruction issue (an MFMA of this shape holds the issue port for 8
-// of its 16 cycles), so everything per residual that is not an MFMA is kept to: two fma (assemble
-// r'), one fma (S2'), one packed convert and one mixed-precision fma (hi / lo split).
+// of its 16 cycles), so everything per residual that is not an MFMA is kept to: one fma (start of the
+// accumulator), one fma (S2'), one packed convert and one mixed-precision fma (hi / lo split).
 // The chip also lowers its clock under this load (1.9 - 1.95 GHz sustained, tools/clock_probe.sh), and more so
 // under a denser one: the same pass on v_mfma_f32_32x32x16_f16 (half the matrix instructions, 32 chains per wave,
 // the accumulator registers 8 s .. 8 s + 7 as the A operand of the second product's k-step s) took the same number
 // of cycles but ran at 1.71 - 1.75 GHz, 6.4 ms against 5.8 ms, and was dropped.
 #include <stdlib.h>
+#include <type_traits>
 #include "bvi_common.h"
 
 namespace {
@@ -85,16 +84,13 @@ struct Header {
   float colscale[64];
   double colsum[64];
   double ysum;
-  float ymax;
+  float ymax;     // max_i |y_i - ybar|
+  float ybar;     // mean of y in f32: the kernels work on y - ybar and on the intercept b0 - ybar
 };
 static_assert(sizeof(Header) <= kGramOffset, "header must fit");
 
-// scale of the residuals for the gradient GEMM: |r| <= ymax + |b0| + D * 2^14 * max|w / colscale|
-__device__ __forceinline__ float resid_scale(float amax_v, float b0, float ymax, int d) {
-  const float bound = ymax + fabsf(b0) + (float)d * 16384.f * amax_v;
-  if (!(bound > 0.f) || !isfinite(bound)) return 1.f;
-  return ldexpf(1.f, min(max(14 - ilogbf(bound), -126), 126));
-}
+// Column scale of the packed plane: |x'| = |x s_d| < 2^(kColTop + 1)
+constexpr int kColTop = 4;
 
 // w / s_d; an all-zero column (s_d = 0) takes no part in the chain's range (0, or NaN for a
 // non-finite weight, as 0 * w would give)
@@ -102,21 +98,48 @@ __device__ __forceinline__ float scaled_weight(float w, float colscale) {
   return colscale > 0.f ? w / colscale : w * 0.f;
 }
 
-__device__ __forceinline__ float pow2_scale(float amax) {
-  // 2^(13 - floor(log2 amax)), kept inside the normal f32 range; 1 for zero / non-finite input
+__device__ __forceinline__ float col_scale(float amax) {
+  // 2^(kColTop - floor(log2 amax)), kept inside the normal f32 range; 1 for zero / non-finite input
   if (!(amax > 0.f) || !isfinite(amax)) return 1.f;
-  return ldexpf(1.f, min(max(13 - ilogbf(amax), -126), 126));
+  return ldexpf(1.f, min(max(kColTop - ilogbf(amax), -126), 126));
 }
 
-// First f16 piece of a scaled weight q (|q| < 2^14): the nearest multiple of kWGrid, or of the f16 spacing at q where
+// The ONE power-of-two scale t of a chain: the kernel works on w'' = -(w / s) t and produces the residuals
+// already scaled, r' = t r, straight out of the matrix instruction.  From the bound that holds for every row,
+//   |r| <= max|y| + |b0| + D 2^(kColTop + 1) max_d |w_d / s_d|,
+// t = 2^(14 - floor(log2 bound)) keeps |r'| < 2^15 and |w''| <= 2^(14 - kColTop) / D inside the f16 range.  The
+// bound is loose by a few binades only, which leaves ~20 binades of f16 range below a typical residual.
+__device__ __forceinline__ float chain_scale(float amax_v, float b0, float ymax, int d) {
+  const float bound = ymax + fabsf(b0) + (float)d * (float)(2 << kColTop) * amax_v;
+  if (!(bound > 0.f) || !isfinite(bound)) return 1.f;
+  return ldexpf(1.f, min(max(14 - ilogbf(bound), -126), 126));
+}
+
+// Target value given to the padding rows of the last tile: the centred intercept of the first chain of the
+// workgroup's chain block (0 if that is not finite)
+__device__ __forceinline__ float pad_target(const float* __restrict__ theta, int first_chain, int dr, float ybar) {
+  const float v = theta[(int64_t)first_chain * (dr + 2)] - ybar;
+  return isfinite(v) ? v : 0.f;
+}
+
+// Grid of the first f16 piece of a chain's scaled weights: 2^-13 of the binade of the largest one (as a pair:
+// the grid and its reciprocal, both powers of two).
+__device__ __forceinline__ void piece_grid(float amax_q, float& grid, float& ginv) {
+  int e = (amax_q > 0.f && isfinite(amax_q)) ? ilogbf(amax_q) - 13 : 0;
+  e = min(max(e, -100), 100);
+  grid = ldexpf(1.f, e);
+  ginv = ldexpf(1.f, -e);
+}
+
+// First f16 piece of a scaled weight q: the nearest multiple of the chain's grid, or of the f16 spacing at q where
 // that is coarser.  A weight far below its chain's largest one thus keeps only a few bits in the first piece (the rest
-// goes to the second piece and the compensated remainder), so that its products with x' carry no bits far below the
+// goes to the compensated remainder), so that its products with x' carry no bits far below the
 // ones of the large products they are summed with: the matrix instruction cuts every addend off, toward zero, a few
 // bits below the largest addend's last bit, which for full-mantissa small products is a loss with a sign.
-constexpr float kWGrid = 1.f;
-__device__ __forceinline__ _Float16 first_piece(float q) {
-  const float g = rintf(q * (1.f / kWGrid)) * kWGrid;
-  return fabsf(q) < 1024.f * kWGrid ? (_Float16)g : (_Float16)q;
+// (The matrix instruction takes f16 subnormals as they are: tools/probes/mfma_subnormal.hip.)
+__device__ __forceinline__ _Float16 first_piece(float q, float grid, float ginv) {
+  const float g = rintf(q * ginv) * grid;
+  return fabsf(q) < 1024.f * grid ? (_Float16)g : (_Float16)q;
 }
 
 // (q0, q1) -> packed f16 (hi0, hi1) and (lo0, lo1) with lo = f16(q - hi): one packed convert and two
@@ -133,14 +156,14 @@ __device__ __forceinline__ void split_pair(float q0, float q1, unsigned& hi, uns
 template <int D, int NW, int CT>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1 ? 3 : 2, CT == 1 ? 3 : 2))) void linreg_f16_kernel(
     const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
-    int nrb, float* __restrict__ partials, float* __restrict__ ublk) {
+    int nrb, float* __restrict__ partials) {
   // D: feature count of the packed planes (32 or 64); dr <= D: the model's feature count (columns dr .. D-1
   // of the planes are zero and take no part)
   constexpr int KS = D / 32;   // k-steps of GEMM1
   constexpr int FT = D / 16;   // feature tiles of GEMM2
   constexpr int SA = 2 * D;    // LDS row stride: no padding, 16-B chunks XOR-swizzled by row (swz below)
   constexpr int IMG = kTileRows * SA;
-  constexpr int BUF = IMG + 2 * kTileRows * 4;       // the plane, u*y, u*valid
+  constexpr int BUF = IMG + kTileRows * 4;           // the plane, y
   constexpr int TPR = D / 8;
   constexpr int NT = 64 * NW;
   constexpr int NCH = kTileRows * TPR;               // 16-B chunks of one plane of a tile
@@ -148,7 +171,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   constexpr int YT = NT / kTileRows;                 // threads staging the same y
   static_assert(NT % kTileRows == 0, "y staging needs a whole number of threads per row");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  __shared__ float sh_u[NW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 15, g = lane >> 4;
@@ -162,12 +184,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   const unsigned char* planes = packed + kHeader;
   const unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
 
-  // scaled -W fragments in two f16 pieces; per chain: c1 = u / t and nb0 = -b0
+  // scaled -W fragments (one f16 piece); per chain: its scale t and nb0t = -t b0
   f16x8 w1[CT][KS];
-  float nb0[CT], c1[CT];
-  float u;
+  float tc[CT];
+  f32x4v nb0v[CT];
   {
-    float umin = INFINITY;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int chain = cbase + 16 * ct + ln;
@@ -184,26 +205,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
         }
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));   // the four lane groups hold the chain's D features
       amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-      const float t = pow2_scale(amax);
-      c1[ct] = 1.f / t;
-      nb0[ct] = cvalid ? -th[0] : 0.f;
-      umin = fminf(umin, resid_scale(amax, cvalid ? th[0] : 0.f, hdr->ymax, D));
+      const float b0 = cvalid ? th[0] - hdr->ybar : 0.f;      // the intercept against the centred targets
+      const float t = chain_scale(amax, b0, hdr->ymax, D);
+      float grid, ginv;
+      piece_grid(amax * t, grid, ginv);
+      tc[ct] = t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nb0v[ct][i] = -b0 * t;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          w1[ct][ks][j] = first_piece(v[ks][j] * t);   // what is left, q - w1, is accounted for in the finalize kernel
+          w1[ct][ks][j] = first_piece(v[ks][j] * t, grid, ginv);   // what is left, q - w1, is accounted for in the finalize kernel
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) umin = fminf(umin, __shfl_xor(umin, off, 64));
-    if (lane == 0) sh_u[wave] = umin;
-    __syncthreads();
-    u = sh_u[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) u = fminf(u, sh_u[w]);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) c1[ct] *= u;
-    if (rbi == 0 && tid == 0) ublk[cbi] = u;
   }
 
   f32x4v G[CT][FT];
@@ -222,7 +236,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   // 8 rows x 32 B) and the 128-bit row stores all spread over the 64 banks without conflicts
   auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
   s16x8 xp[PER];
-  float yp, mp;
+  float yp;
+  const float ybar = hdr->ybar;
+  const float ypad = pad_target(theta, cbi * (16 * CT * NW), dr, ybar);
   auto gload = [&](int64_t tile) {
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
 #pragma unroll
@@ -233,8 +249,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     }
     // every thread stages a y (NW threads per row, same value): an unconditional use keeps the
     // compiler from sinking this load down to the store, where its latency would be exposed
+    // padding rows (x = 0): G' gains nothing from them; with the target set to the centred intercept of the
+    // workgroup's first chain their residuals, t (ypad - (b0 - ybar)), are zero for that chain and of the size of
+    // the chains' spread for the others -- small next to the real rows' sum -- and the finalize kernel takes
+    // their squares out of S2' again
     yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
-    mp = row0 + tid / YT < n ? u : 0.f;     // padding rows: x = 0, y = 0, and no -b0 either -> r' = 0
+    yp = row0 + tid / YT < n ? yp - ybar : ypad;
   };
   auto lstore = [&](int buf) {
     unsigned char* base = lds + buf * BUF;
@@ -245,8 +265,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
       if (NCH % NT == 0 || idx < NCH)
         *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
     }
-    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yp * u;
-    *reinterpret_cast<float*>(base + IMG + kTileRows * 4 + (tid / YT) * 4) = mp;
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yp;
   };
 
   int64_t tile = rbi;
@@ -286,31 +305,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
       const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
       xh[slot] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    // GEMM1, then r' = z' (u / t) + (u y - u b0): scaled residuals of this wave's 64 rows x 32 chains
+    // GEMM1 on top of -t b0, plus t y: the scaled residuals r' = t (y - b0 - xh . w1) of this wave's 64 rows x 32 chains
     load_a(0, 0);
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       const f32x4v yv = *reinterpret_cast<const f32x4v*>(base + IMG + (ro + 16 * rt + 4 * g) * 4);
-      const f32x4v mv = *reinterpret_cast<const f32x4v*>(base + IMG + kTileRows * 4 + (ro + 16 * rt + 4 * g) * 4);
       if (rt < 3) load_a(rt + 1, (rt + 1) & 1);
       else { load_x(0, 0, 0); load_x(0, 1, 1); }
       __builtin_amdgcn_sched_barrier(0);
-      f32x4v z[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[ct][i] = 0.f;
+      // the accumulator starts at -t b0 (a register constant: no instruction), t y is added afterwards in f32:
+      // inside the matrix instruction the large t y would set the exponent every product is cut off at
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          z[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], z[ct], 0, 0, 0);
+          Z[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt & 1][ks], w1[ct][ks], ks == 0 ? nb0v[ct] : Z[rt][ct],
+                                                             0, 0, 0);
         }
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Z[rt][ct][i] = fmaf(z[ct][i], c1[ct], fmaf(mv[i], nb0[ct], yv[i]));
+        for (int i = 0; i < 4; ++i) Z[rt][ct][i] = fmaf(yv[i], tc[ct], Z[rt][ct][i]);
     }
     // GEMM2: G' += R'^T Xh' over the two 32-row pairs (the low plane's share is added in closed form by the
     // finalize kernel)
@@ -372,6 +388,309 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   }
 }
 
+// ---- the same pass, software-pipelined (many chains: two 16-chain tiles per wave) ----
+// The loop above runs its three stages one after the other -- residual GEMM (matrix + vector work), hi / lo split
+// (vector work only), gradient GEMM (matrix work only) -- so a wave leaves the matrix pipe idle while it splits and
+// the vector ALU idle while it multiplies, and the two waves of a SIMD, released by the same barrier, do so at the
+// same time; LDS fragments are fetched one short step ahead and their latency shows.  Here the tile is cut into 32-row
+// UNITS and three consecutive units are in flight per wave.  In block j the wave issues, instruction by instruction
+// interleaved,
+//     R(j-1): the gradient GEMM of the unit whose residuals were split in the previous block      (2 FT CT MFMAs)
+//     Q(j)  : + t y, sum of squares and hi / lo split of the unit the previous block multiplied   (56 vector ops)
+//     P(j+1): the residual GEMM of the next unit                                                  (2 KS CT MFMAs)
+// and the LDS reads of everything block j+1 will consume -- a whole block (~400 cycles) ahead.  The three streams are
+// independent inside a block, so the order below is fixed by hand: per group of three slots two R MFMAs and one P MFMA,
+// each followed by the 2 - 3 vector instructions that fit into the 8 issue cycles an MFMA of this shape leaves free.
+// Units cross tile boundaries (the last units of a tile are multiplied while the next tile's first unit is read), so
+// the staged tiles live in a ring of three LDS buffers, filled two tiles ahead; still one barrier per tile.
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_pipe_kernel(
+    const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
+    int nrb, float* __restrict__ partials) {
+  constexpr int CT = 2;
+  constexpr int KS = D / 32;   // k-steps of the residual GEMM
+  constexpr int FT = D / 16;   // feature tiles of the gradient GEMM
+  constexpr int SA = 2 * D;    // LDS row stride (16-B chunks XOR-swizzled by row, as above)
+  constexpr int IMG = kTileRows * SA;
+  constexpr int BUF = IMG + kTileRows * 4;
+  constexpr int RING = 3;
+  constexpr int TPR = D / 8;
+  constexpr int NT = 64 * NW;
+  constexpr int NCH = kTileRows * TPR;
+  constexpr int PER = (NCH + NT - 1) / NT;
+  constexpr int YT = NT / kTileRows;
+  constexpr int UPT = kTileRows / 32;          // units per tile
+  constexpr int NP = 2 * CT * KS;              // P MFMAs per block
+  constexpr int NS = 3 * NP;                   // slots (= MFMAs) per block: two R per P
+  constexpr int NG = NS / 3;                   // groups of three slots
+  constexpr int JPG = 4 * CT / NG;             // hi / lo jobs (pairs of residuals of one chain tile) per group
+  static_assert(2 * FT * CT == 2 * NP && NT % kTileRows == 0 && UPT == 4 && (4 * CT) % NG == 0, "schedule shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, g = lane >> 4;
+  const int x8 = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
+  const int cbase = cbi * (16 * CT * NW) + 16 * CT * wave;
+  const Header* hdr = reinterpret_cast<const Header*>(packed);
+  const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+  const int64_t n_pad = ntiles * kTileRows;
+  const unsigned char* planes = packed + kHeader;
+  const unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
+
+  f16x8 w1[CT][KS];
+  float tc[CT];
+  f32x4v nb0v[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int chain = cbase + 16 * ct + ln;
+    const bool cvalid = chain < C;
+    const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
+    float v[KS][8], amax = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int f = 32 * ks + 8 * g + j;
+        v[ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
+        amax = fmaxf(amax, fabsf(v[ks][j]));
+      }
+    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    const float b0 = cvalid ? th[0] - hdr->ybar : 0.f;
+    const float t = chain_scale(amax, b0, hdr->ymax, D);
+    float grid, ginv;
+    piece_grid(amax * t, grid, ginv);
+    tc[ct] = t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nb0v[ct][i] = -b0 * t;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w1[ct][ks][j] = first_piece(v[ks][j] * t, grid, ginv);
+  }
+
+  f32x4v G[CT][FT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G[ct][ft][i] = 0.f;
+  float s2[CT] = {0.f, 0.f}, a2[CT] = {0.f, 0.f};
+
+  // tiles of this row block: rbi, rbi + nrb, ...
+  const int64_t nt = rbi < ntiles ? (ntiles - rbi + nrb - 1) / nrb : 0;
+
+  // ---- staging: global -> registers -> LDS ring ----
+  auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
+  s16x8 xp[PER];
+  float yp;
+  const float ybar = hdr->ybar;
+  const float ypad = pad_target(theta, cbi * (16 * CT * NW), dr, ybar);
+  auto gload = [&](int64_t k) {      // k-th tile of this row block; past the end: tile 0 of the dataset, never used
+    const int64_t tile = rbi + k * nrb;
+    const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int idx = tid + e * NT;
+      const int srow = (NCH % NT == 0 || idx < NCH) ? idx / TPR : 0, ch = idx % TPR;
+      xp[e] = *reinterpret_cast<const s16x8*>(planes + ((row0 + srow) * D + ch * 8) * 2);
+    }
+    yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
+    yp = row0 + tid / YT < n ? yp - ybar : ypad;
+  };
+  auto lstore = [&](int ring) {
+    unsigned char* base = lds + ring * BUF;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int idx = tid + e * NT;
+      const int srow = idx / TPR, ch = idx % TPR;
+      if (NCH % NT == 0 || idx < NCH)
+        *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
+    }
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yp;
+  };
+
+  // ---- per-lane LDS offsets of the three kinds of fragment inside a tile image (unit 0) ----
+  int offA[KS], offX[FT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) offA[ks] = ln * SA + (((4 * ks + g) ^ swz(ln)) << 4);
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    const int trow = 4 * g + (ln >> 2);       // swz(trow + 16) == swz(trow)
+    offX[ft] = trow * SA + (((2 * ft + ((ln & 3) >> 1)) ^ swz(trow)) << 4) + 8 * (ln & 1);
+  }
+  const int offY = IMG + 16 * g;
+
+  // fragment sets, indexed by block parity (all indices are compile-time constants: registers)
+  f32x4v Z[2][2][CT];          // scaled residuals of a unit: [set][row tile][chain tile]
+  unsigned RH[2][CT][4], RL[2][CT][4];
+  s16x4 XH[2][FT][2];          // the two 16-row halves of a transposed fragment
+  f16x8 A[2][2][KS];
+  f32x4v YV[2][2];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  auto read_a = [&](const unsigned char* img, int unit, int rt, int ks) {
+    return *reinterpret_cast<const f16x8*>(img + (32 * unit + 16 * rt) * SA + offA[ks]);
+  };
+  auto read_y = [&](const unsigned char* img, int unit, int rt) {
+    return *reinterpret_cast<const f32x4v*>(img + (32 * unit + 16 * rt) * 4 + offY);
+  };
+  auto read_x_half = [&](const unsigned char* img, int unit, int ft, int half) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (32 * unit + 16 * half) * SA + offX[ft]));
+  };
+
+  if (nt > 0) {
+    // prologue: tiles 0 and 1 into the ring; P of unit 0; fragments of what block 0 consumes
+    gload(0); lstore(0);
+    gload(1); lstore(1);
+    __syncthreads();
+    {
+      const unsigned char* img = lds;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f16x8 a0[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a0[ks] = read_a(img, 0, rt, ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            Z[0][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], w1[ct][ks], ks == 0 ? nb0v[ct] : Z[0][rt][ct],
+                                                                  0, 0, 0);
+        YV[0][rt] = read_y(img, 0, rt);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) A[1][rt][ks] = read_a(img, 1, rt, ks);
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { RH[1][ct][i] = 0u; RL[1][ct][i] = 0u; }
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) XH[1][ft][h] = (s16x4){0, 0, 0, 0};
+    }
+
+    int rcur = 0;                                  // ring slot of the tile being processed
+    for (int64_t k = 0; k < nt; ++k) {
+      gload(k + 2);
+      const int rnxt = rcur == RING - 1 ? 0 : rcur + 1;
+      const unsigned char* icur = lds + rcur * BUF;
+      const unsigned char* inxt = lds + rnxt * BUF;
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<UPT>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int sq = j & 1, sr = (j + 1) & 1;      // sets: Q / loads of XH, A  |  R, P, loads of YV
+        // unit whose A fragments are read (for the P of the next block) and whose y is read (for its Q)
+        constexpr int ua = (j + 2) % UPT, uy = (j + 1) % UPT;
+        const unsigned char* ia = j + 2 < UPT ? icur : inxt;
+        const unsigned char* iy = j + 1 < UPT ? icur : inxt;
+        static_for<NS>([&](auto sc_) {
+          constexpr int s = decltype(sc_)::value;
+          constexpr int grp = s / 3, r = s % 3;
+          // -- LDS reads for the next block
+          constexpr int xslots = NS / FT, aslots = NS / (2 * KS);
+          if constexpr (s % xslots < 2) {
+            constexpr int ft = s / xslots, half = s % xslots;
+            XH[sq][ft][half] = read_x_half(icur, j, ft, half);
+          }
+          if constexpr (s % aslots == 2) {
+            constexpr int i = s / aslots, rt = i / KS, ks = i % KS;
+            A[sq][rt][ks] = read_a(ia, ua, rt, ks);
+          }
+          if constexpr (s == 3 || s == 9) {
+            constexpr int rt = s == 3 ? 0 : 1;
+            YV[sr][rt] = read_y(iy, uy, rt);
+          }
+          // -- the slot's MFMA
+          if constexpr (r == 2) {                          // P(j+1): row tile rt, k-step ks, chain tile ct
+            constexpr int rt = grp / (CT * KS), ks = (grp / CT) % KS, ct = grp % CT;
+            Z[sr][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[sr][rt][ks], w1[ct][ks],
+                                                                   ks == 0 ? nb0v[ct] : Z[sr][rt][ct], 0, 0, 0);
+          } else {                                         // R(j-1): feature tile ft, piece, chain tile ct
+            constexpr int q = 2 * grp + r, ft = q / (2 * CT), piece = (q % (2 * CT)) / CT, ct = q % CT;
+            const f16x8 rv = piece == 0
+                ? __builtin_bit_cast(f16x8, (u32x4){RH[sr][ct][0], RH[sr][ct][1], RH[sr][ct][2], RH[sr][ct][3]})
+                : __builtin_bit_cast(f16x8, (u32x4){RL[sr][ct][0], RL[sr][ct][1], RL[sr][ct][2], RL[sr][ct][3]});
+            const f16x8 xv = __builtin_bit_cast(
+                f16x8, __builtin_shufflevector(XH[sr][ft][0], XH[sr][ft][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rv, xv, G[ct][ft], 0, 0, 0);
+          }
+          // -- the slot's share of Q(j): job = (chain tile ct, residual pair jp) -> element pair of Z[sq]
+          static_for<JPG>([&](auto jb_) {
+            constexpr int job = grp * JPG + decltype(jb_)::value;      // 0 .. 4 CT - 1, row tile 0 first
+            constexpr int jp = job / CT, ct = job % CT;                // pair jp: k = 2 jp, 2 jp + 1 of the A fragment
+            constexpr int rt = jp >> 1, i0 = 2 * (jp & 1);
+            if constexpr (r == 0) {
+              Z[sq][rt][ct][i0] = fmaf(YV[sq][rt][i0], tc[ct], Z[sq][rt][ct][i0]);
+              Z[sq][rt][ct][i0 + 1] = fmaf(YV[sq][rt][i0 + 1], tc[ct], Z[sq][rt][ct][i0 + 1]);
+            } else if constexpr (r == 1) {
+              const float q0 = Z[sq][rt][ct][i0], q1 = Z[sq][rt][ct][i0 + 1];
+              a2[ct] = fmaf(q0, q0, a2[ct]);
+              a2[ct] = fmaf(q1, q1, a2[ct]);
+            } else {
+              const float q0 = Z[sq][rt][ct][i0], q1 = Z[sq][rt][ct][i0 + 1];
+              unsigned hi, lo;
+              asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(q0), "v"(q1));
+              asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(q0), "v"(hi));
+              asm("v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(lo) : "0"(lo), "v"(q1), "v"(hi));
+              RH[sq][ct][jp] = hi;
+              RL[sq][ct][jp] = lo;
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) { s2[ct] += a2[ct]; a2[ct] = 0.f; }
+      lstore(rnxt == RING - 1 ? 0 : rnxt + 1);
+      __syncthreads();
+      rcur = rnxt;
+    }
+    // epilogue: the gradient GEMM of the last unit
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const f16x8 rh = __builtin_bit_cast(f16x8, (u32x4){RH[1][ct][0], RH[1][ct][1], RH[1][ct][2], RH[1][ct][3]});
+        const f16x8 rl = __builtin_bit_cast(f16x8, (u32x4){RL[1][ct][0], RL[1][ct][1], RL[1][ct][2], RL[1][ct][3]});
+        const f16x8 xv = __builtin_bit_cast(f16x8, __builtin_shufflevector(XH[1][ft][0], XH[1][ft][1], 0, 1, 2, 3, 4, 5, 6, 7));
+        G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh, xv, G[ct][ft], 0, 0, 0);
+        G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl, xv, G[ct][ft], 0, 0, 0);
+      }
+  }
+
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float v = s2[ct];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int chain = cbase + 16 * ct + ln;
+    if (chain < C && g == 0) {
+      float* p = partials + ((int64_t)rbi * C + chain) * (dr + 2);
+      p[0] = v;
+      p[1] = 0.f;
+    }
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = cbase + 16 * ct + 4 * g + i;
+        if (c < C && 16 * ft + ln < dr) partials[((int64_t)rbi * C + c) * (dr + 2) + 2 + 16 * ft + ln] = G[ct][ft][i];
+      }
+  }
+}
+
 // ---- pack: column statistics (two-stage, fixed order) then the split ----
 // stage 1: block b reduces rows b, b + nblk, ... : per column abs-max and sum (double), sum and abs-max of y
 template <int D>
@@ -381,7 +700,7 @@ __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __
   constexpr int RL = 256 / D;
   const int col = threadIdx.x % D, rl = threadIdx.x / D;
   float amax = 0.f;
-  float ymax = 0.f;
+  float yhi = -INFINITY, ylo = INFINITY;      // largest and smallest y (NaN: kept out by fmaxf / fminf, found by ysum)
   double sum = 0.0, ysum = 0.0;
   for (int64_t row = (int64_t)blockIdx.x * RL + rl; row < n; row += (int64_t)gridDim.x * RL) {
     const float v = col < dr ? X[row * dr + col] : 0.f;
@@ -389,15 +708,17 @@ __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __
     sum += (double)v;
     if (col == 0) {
       ysum += (double)y[row];
-      ymax = fmaxf(ymax, fabsf(y[row]));
+      yhi = fmaxf(yhi, y[row]);
+      ylo = fminf(ylo, y[row]);
     }
   }
-  __shared__ float smax[256], symax[256];
+  __shared__ float smax[256], syhi[256], sylo[256];
   __shared__ double ssum[256], sy[256];
   smax[threadIdx.x] = amax;
   ssum[threadIdx.x] = sum;
   sy[threadIdx.x] = ysum;
-  symax[threadIdx.x] = ymax;
+  syhi[threadIdx.x] = yhi;
+  sylo[threadIdx.x] = ylo;
   __syncthreads();
   if (rl == 0) {
     for (int q = 1; q < RL; ++q) {
@@ -405,11 +726,15 @@ __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __
       sum += ssum[q * D + col];
       if (col == 0) {
         ysum += sy[q * D];
-        ymax = fmaxf(ymax, symax[q * D]);
+        yhi = fmaxf(yhi, syhi[q * D]);
+        ylo = fminf(ylo, sylo[q * D]);
       }
     }
-    pmax[(int64_t)blockIdx.x * (D + 1) + col] = amax;
-    if (col == 0) pmax[(int64_t)blockIdx.x * (D + 1) + D] = ymax;
+    pmax[(int64_t)blockIdx.x * (D + 2) + col] = amax;
+    if (col == 0) {
+      pmax[(int64_t)blockIdx.x * (D + 2) + D] = yhi;
+      pmax[(int64_t)blockIdx.x * (D + 2) + D + 1] = ylo;
+    }
     psum[(int64_t)blockIdx.x * (D + 1) + col] = sum;
     if (col == 0) psum[(int64_t)blockIdx.x * (D + 1) + D] = ysum;
   }
@@ -417,16 +742,16 @@ __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __
 
 template <int D>
 __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* __restrict__ psum, int nblk,
-                                    Header* __restrict__ hdr) {
+                                    int64_t n, Header* __restrict__ hdr) {
   const int col = threadIdx.x;
   if (col < D) {
     float amax = 0.f;
     double sum = 0.0;
     for (int b = 0; b < nblk; ++b) {
-      amax = fmaxf(amax, pmax[(int64_t)b * (D + 1) + col]);
+      amax = fmaxf(amax, pmax[(int64_t)b * (D + 2) + col]);
       sum += psum[(int64_t)b * (D + 1) + col];
     }
-    hdr->colscale[col] = amax > 0.f ? pow2_scale(amax) : 0.f;   // 0 marks an all-zero column
+    hdr->colscale[col] = amax > 0.f ? col_scale(amax) : 0.f;   // 0 marks an all-zero column
     hdr->colsum[col] = sum;
   } else if (col < 64) {
     hdr->colscale[col] = 0.f;
@@ -434,13 +759,16 @@ __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* 
   }
   if (col == 0) {
     double ys = 0.0;
-    float ym = 0.f;
+    float yhi = -INFINITY, ylo = INFINITY;
     for (int b = 0; b < nblk; ++b) {
       ys += psum[(int64_t)b * (D + 1) + D];
-      ym = fmaxf(ym, pmax[(int64_t)b * (D + 1) + D]);
+      yhi = fmaxf(yhi, pmax[(int64_t)b * (D + 2) + D]);
+      ylo = fminf(ylo, pmax[(int64_t)b * (D + 2) + D + 1]);
     }
+    const float ybar = n > 0 ? (float)(ys / (double)n) : 0.f;
     hdr->ysum = ys;
-    hdr->ymax = ym;
+    hdr->ybar = isfinite(ybar) ? ybar : 0.f;
+    hdr->ymax = n > 0 ? fmaxf(fabsf(yhi - hdr->ybar), fabsf(ylo - hdr->ybar)) : 0.f;
   }
 }
 
@@ -632,7 +960,7 @@ __global__ void f16_low_final(const double* __restrict__ lpart, int nblk, int D,
 // are many (all workgroups resident at once).
 template <int kFinGroups>
 __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
-    const float* __restrict__ partials, const float* __restrict__ ublk, int cpb, int nb, int64_t n, int d,
+    const float* __restrict__ partials, int nb, int64_t n, int d, int dplane, int cpb,
     const unsigned char* __restrict__ packed, const float* __restrict__ theta, int C, float* __restrict__ logp,
     float* __restrict__ grad) {
   const int c = blockIdx.x, q2 = d + 2;
@@ -640,6 +968,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
   __shared__ double part[5][kFinGroups][64];
   __shared__ double sums[66], dw[64], wv[64], s2t[64];
+  __shared__ float sh_t;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
   const double* low = reinterpret_cast<const double*>(packed + kLowOffset);
@@ -652,11 +981,14 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     float amax = fabsf(v);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-    const float t = pow2_scale(amax);
+    const float t = chain_scale(amax, th[0] - hdr->ybar, hdr->ymax, dplane);
+    float grid, ginv;
+    piece_grid(amax * t, grid, ginv);
     const float q = v * t;
-    const float rem = q - (float)first_piece(q);        // exact: the piece is q rounded to a coarser grid
+    const float rem = q - (float)first_piece(q, grid, ginv);        // exact: the piece is q rounded to a coarser grid
     dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;
     wv[o] = o < d ? (double)th[1 + o] : 0.0;
+    if (o == 0) sh_t = t;
   }
   for (int q0 = 0; q0 < q2; q0 += 64) {
     const int q = q0 + o;
@@ -673,7 +1005,11 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     }
     __syncthreads();
   }
-  const double u = (double)ublk[c / cpb];
+  const double u = (double)sh_t;       // the chain's scale: S2' = t^2 S2_k, G'_f = t s_f G_k,f
+  // the kernel's intercept is ybar + fl32(b0 - ybar); what that leaves of b0 is handled like dw, in closed form
+  const float b0c = th[0] - hdr->ybar;
+  const double b0_eff = (double)hdr->ybar + (double)b0c;
+  const double db = (double)th[0] - b0_eff;
   const double sc = (double)th[d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   {
@@ -705,19 +1041,27 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
       m[k] = part[k][0][f];
       for (int w = 1; w < kFinGroups; ++w) m[k] += part[k][w][f];
     }
-    // kernel: r_k = y - b0 - xh.wk with wk = w - dw, G_k = sum xh r_k (G'_f = u s_f G_k,f).  The true residual is
-    // r = r_k - (xr.w + xh.dw), hence
-    //   G = G_k - A wk - (X^T X) dw + t1,   t1 = XR^T y - b0 XR^T 1
-    //   S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B wk + dw . (X^T X - A) dw),   cr = t1 - B wk
+    // kernel: r_k = y - b0_eff - xh.wk with wk = w - dw and b0_eff = b0 - db, G_k = sum xh r_k
+    // (G'_f = t s_f G_k,f).  The true residual is r = r_k - (db + xr.w + xh.dw), hence
+    //   G = G_k - A wk - (X^T X) dw + t1 - db XH^T 1,   t1 = XR^T y - b0 XR^T 1,   XH^T 1 = X^T 1 - XR^T 1
+    //   S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B wk + dw . (X^T X - A) dw)
+    //        - 2 db (sum y - n b0_eff - w . XH^T 1) + n db^2,   cr = t1 + db XR^T 1 - B wk = sum xr r_k
     const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;
-    const double t1 = low[8192 + f] - (double)th[0] * low[8192 + 64 + f];
+    const double xr1 = low[8192 + 64 + f];
+    const double sxh = hdr->colsum[f] - xr1;
+    const double t1 = low[8192 + f] - (double)th[0] * xr1;
     const double bwk = m[3] - m[4];
-    s2t[f] = -2.0 * (wv[f] * (t1 - bwk) + dw[f] * g0) + wv[f] * (m[1] - 2.0 * bwk) + dw[f] * (m[0] - m[2]);
-    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - (m[1] - m[2]) - m[0] + t1) * inv2);
+    s2t[f] = -2.0 * (wv[f] * (t1 + db * xr1 - bwk) + dw[f] * g0) + wv[f] * (m[1] - 2.0 * bwk) + dw[f] * (m[0] - m[2]) +
+             2.0 * db * wv[f] * sxh;
+    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - (m[1] - m[2]) - m[0] + t1 - db * sxh) * inv2);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s2 = sums[0] / (u * u);       // S2' = u^2 S2
+    // padding rows of the last tile came through as r' = fma(ypad, t, -t (b0 - ybar)): out again
+    const double npad = (double)((n + kTileRows - 1) / kTileRows * kTileRows - n);
+    const float rpad = fmaf(pad_target(theta, (c / cpb) * cpb, d, hdr->ybar), sh_t, -b0c * sh_t);
+    double s2 = (sums[0] - npad * (double)rpad * (double)rpad) / (u * u);
+    s2 += -2.0 * db * (hdr->ysum - nn * b0_eff) + nn * db * db;
     for (int f = 0; f < d; ++f) s2 += s2t[f];
     logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
@@ -744,7 +1088,7 @@ size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
 // scratch for the column statistics of the pack step (bytes)
 size_t bvi_linreg_f16_pack_scratch(int d) {
   const int dp = plane_cols(d);
-  return (size_t)kStatBlocks * (dp + 1) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
+  return (size_t)kStatBlocks * (dp + 2) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
          (size_t)kGramBlocks * (64 * 64 + kLowStride) * sizeof(double) + 16;
 }
 
@@ -768,14 +1112,14 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   if (dp == 64) {
     hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
     hipLaunchKernelGGL(f16_header_kernel<64>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
-                       kStatBlocks, (Header*)packed);
+                       kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
     hipLaunchKernelGGL(f16_gram_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
     hipLaunchKernelGGL(f16_low_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
   } else {
     hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
     hipLaunchKernelGGL(f16_header_kernel<32>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
-                       kStatBlocks, (Header*)packed);
+                       kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
     hipLaunchKernelGGL(f16_gram_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
     hipLaunchKernelGGL(f16_low_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
@@ -799,29 +1143,35 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   int per8 = (max_blocks / 8) / ncb;
   if (per8 < 1) per8 = 1;
   const int nrb = 8 * per8;
-  // workspace: partials [nrb][c][d+2], then one residual scale per chain block
-  float* ublk = ws + (size_t)nrb * c * (d + 2);
-  const size_t lds = 2 * (size_t)(kTileRows * 2 * D + 2 * kTileRows * 4);
+  // workspace: partials [nrb][c][d+2]
+  constexpr bool pipelined = CT == 2;      // many chains: the software-pipelined form of the pass, 3 staged tiles
+  const size_t lds = (pipelined ? 3 : 2) * (size_t)(kTileRows * 2 * D + kTileRows * 4);
   // > 64 KB of dynamic LDS has to be allowed once per kernel and device (setting it twice from two threads is
   // harmless)
   static bool lds_ok[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return BVI_ERR_ARG;
   if (!lds_ok[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW, CT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = pipelined ? hipFuncSetAttribute((const void*)&linreg_f16_pipe_kernel<D, NW>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                             : hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW, CT>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     lds_ok[dev] = true;
   }
-  hipLaunchKernelGGL((linreg_f16_kernel<D, NW, CT>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb, nrb,
-                     ws, ublk);
+  if constexpr (pipelined)
+    hipLaunchKernelGGL((linreg_f16_pipe_kernel<D, NW>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb,
+                       nrb, ws);
+  else
+    hipLaunchKernelGGL((linreg_f16_kernel<D, NW, CT>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb,
+                       nrb, ws);
   BVI_HIP_CHECK_LAUNCH();
   if (c > 256)
-    hipLaunchKernelGGL(linreg_f16_finalize<4>, dim3(c), dim3(256), 0, s, (const float*)ws, (const float*)ublk, cpb,
-                       nrb, n, d, pk, theta, c, logp, grad);
+    hipLaunchKernelGGL(linreg_f16_finalize<4>, dim3(c), dim3(256), 0, s, (const float*)ws, nrb, n, d, D, cpb, pk, theta,
+                       c, logp, grad);
   else
-    hipLaunchKernelGGL(linreg_f16_finalize<16>, dim3(c), dim3(1024), 0, s, (const float*)ws, (const float*)ublk, cpb,
-                       nrb, n, d, pk, theta, c, logp, grad);
+    hipLaunchKernelGGL(linreg_f16_finalize<16>, dim3(c), dim3(1024), 0, s, (const float*)ws, nrb, n, d, D, cpb, pk, theta,
+                       c, logp, grad);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

@@ -394,7 +394,7 @@ def test_fused_hmc_through_mcmc_fit_posterior_moments(bvi):
     hmc = bvi.HamiltonianMonteCarlo(step_size=0.1, num_leapfrog_steps=8,
                                     stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(300))
     mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=hmc)
-    kernel, _ = hmc(mcmc.posterior.unconstrained_log_prob_and_grad)
+    kernel, _, _ = hmc(mcmc.posterior.unconstrained_log_prob_and_grad)
     assert isinstance(kernel.inner, FusedHamiltonianMonteCarloKernel)
     res = mcmc.fit(num_chains=8, num_samples=4000, num_burnin_steps=500, progress_bar=False, seed=3)
     loc, scale = (s.cpu().numpy() for s in res.samples)
@@ -610,8 +610,9 @@ def test_batched_device_nuts_through_mcmc_fit_on_a_large_regression(bvi, gpu_dev
     cfg = bvi.NoUTurnSampler(step_size=0.002, max_tree_depth=5,
                              stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(num_adaptation_steps=150))
     mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=cfg)
-    kernel, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
+    kernel, trace_fns, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
     assert isinstance(kernel.inner, BatchedDeviceNoUTurnSamplerKernel)
+    assert len(trace_fns) == 2 and all(callable(f) for f in trace_fns)      # (kernel, trace_fns, trace_metrics), transition_kernels.py:24-38
     from bayes_vi_amd.inference.mcmc.device_hmc import DeviceRandomWalkMetropolisKernel
     rwm = bvi.RandomWalkMetropolis()(mcmc.posterior.unconstrained_log_prob_and_grad)[0]
     assert isinstance(getattr(rwm, 'inner', rwm), DeviceRandomWalkMetropolisKernel)
@@ -638,7 +639,7 @@ def test_fused_nuts_through_mcmc_fit(bvi):
     model, ds = normal_setup(bvi, y)
     cfg = bvi.NoUTurnSampler(stepsize_adaptation_kernel=bvi.DualAveragingStepSizeAdaptation(num_adaptation_steps=800))
     mcmc = bvi.MCMC(model=model, dataset=ds, transition_kernel=cfg)
-    kernel, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
+    kernel, trace_fns, names = cfg(mcmc.posterior.unconstrained_log_prob_and_grad)
     assert isinstance(kernel.inner, FusedNoUTurnSamplerKernel)
     res = mcmc.fit(num_chains=2, num_samples=4000, num_burnin_steps=1000, progress_bar=False, seed=5)
     loc, scale = (s.cpu().numpy() for s in res.samples)

@@ -241,7 +241,11 @@ def test_linreg_f16_pieces_high_signal_to_noise(nat, ws, gpu_device, sigma):
     e16 = (np.abs(g - ref_g)[:, 1:1 + d] / scale).max()
     e32 = (np.abs(g32.cpu().numpy() - ref_g)[:, 1:1 + d] / scale).max()
     assert e16 <= 2.0 * e32 + 1e-6, (e16, e32)
-    assert (np.abs(lp - ref_lp) / np.abs(ref_lp)).max() <= 2e-6        # 1e-5 bar with room to spare
+    # the log-density: inside the 1e-5 bar with room to spare, and at the level of the exact-f32 kernel's own error
+    # (at signal / noise ~ 8000 both are set by the f32 rounding of the fitted values: ~1.5e-6 for that kernel)
+    rel = (np.abs(lp - ref_lp) / np.abs(ref_lp)).max()
+    rel32 = (np.abs(lp32.cpu().numpy() - ref_lp) / np.abs(ref_lp)).max()
+    assert rel <= 5e-6 and rel <= 2.0 * rel32 + 1e-6, (rel, rel32)
     # d logp / d scale = -n / s + S2 / s^3 is a difference of two equal terms at the mode, so it shows the error of
     # S2 itself; any f32 evaluation rounds the fitted values to ~1e-7 of their size, which is ~1e-3 of a residual
     # at signal / noise 5000 and averages down with sqrt(n): the exact-f32 kernel sets the scale here too
