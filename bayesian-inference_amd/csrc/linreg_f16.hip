@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
   s16x8 xp[PER];
   float yp;
+  bool yvalid;
   const float ybar = hdr->ybar;
   const float ypad = pad_target(theta, cbi * (16 * CT * NW), dr, ybar);
   auto gload = [&](int64_t tile) {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     // the chains' spread for the others -- small next to the real rows' sum -- and the finalize kernel takes
     // their squares out of S2' again
     yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
-    yp = row0 + tid / YT < n ? yp - ybar : ypad;
+    yvalid = row0 + tid / YT < n;      // (the arithmetic on yp waits until the store: no wait for the load here)
   };
   auto lstore = [&](int buf) {
     unsigned char* base = lds + buf * BUF;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
       if (NCH % NT == 0 || idx < NCH)
         *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
     }
-    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yp;
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid ? yp - ybar : ypad;
   };
 
   int64_t tile = rbi;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
   s16x8 xp[PER];
   float yp;
+  bool yvalid;
   const float ybar = hdr->ybar;
   const float ypad = pad_target(theta, cbi * (16 * CT * NW), dr, ybar);
   auto gload = [&](int64_t k) {      // k-th tile of this row block; past the end: tile 0 of the dataset, never used
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       xp[e] = *reinterpret_cast<const s16x8*>(planes + ((row0 + srow) * D + ch * 8) * 2);
     }
     yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
-    yp = row0 + tid / YT < n ? yp - ybar : ypad;
+    yvalid = row0 + tid / YT < n;      // (the arithmetic on yp waits until the store: no wait for the load here)
   };
   auto lstore = [&](int ring) {
     unsigned char* base = lds + ring * BUF;
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (NCH % NT == 0 || idx < NCH)
         *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
     }
-    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yp;
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid ? yp - ybar : ypad;
   };
 
   // ---- per-lane LDS offsets of the three kinds of fragment inside a tile image (unit 0) ----
