@@ -633,20 +633,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             constexpr int job = grp * JPG + decltype(jb_)::value;      // 0 .. 4 CT - 1, row tile 0 first
             constexpr int jp = job / CT, ct = job % CT;                // pair jp: k = 2 jp, 2 jp + 1 of the A fragment
             constexpr int rt = jp >> 1, i0 = 2 * (jp & 1);
+            // balanced over the group's three MFMA gaps by issue cost (the mixed-precision fma costs ~2.6 plain ones):
+            // [+ t y, + t y, convert]  [square, low piece of the first]  [square, low piece of the second]
             if constexpr (r == 0) {
               Z[sq][rt][ct][i0] = fmaf(YV[sq][rt][i0], tc[ct], Z[sq][rt][ct][i0]);
               Z[sq][rt][ct][i0 + 1] = fmaf(YV[sq][rt][i0 + 1], tc[ct], Z[sq][rt][ct][i0 + 1]);
-            } else if constexpr (r == 1) {
               const float q0 = Z[sq][rt][ct][i0], q1 = Z[sq][rt][ct][i0 + 1];
-              a2[ct] = fmaf(q0, q0, a2[ct]);
-              a2[ct] = fmaf(q1, q1, a2[ct]);
-            } else {
-              const float q0 = Z[sq][rt][ct][i0], q1 = Z[sq][rt][ct][i0 + 1];
-              unsigned hi, lo;
+              unsigned hi;
               asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(q0), "v"(q1));
-              asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(q0), "v"(hi));
-              asm("v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(lo) : "0"(lo), "v"(q1), "v"(hi));
               RH[sq][ct][jp] = hi;
+            } else if constexpr (r == 1) {
+              const float q0 = Z[sq][rt][ct][i0];
+              const unsigned hi = RH[sq][ct][jp];
+              unsigned lo;
+              a2[ct] = fmaf(q0, q0, a2[ct]);
+              asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(q0), "v"(hi));
+              RL[sq][ct][jp] = lo;
+            } else {
+              const float q1 = Z[sq][rt][ct][i0 + 1];
+              const unsigned hi = RH[sq][ct][jp];
+              unsigned lo = RL[sq][ct][jp];
+              a2[ct] = fmaf(q1, q1, a2[ct]);
+              asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(q1), "v"(hi));
               RL[sq][ct][jp] = lo;
             }
           });
