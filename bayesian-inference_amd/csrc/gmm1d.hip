@@ -15,169 +15,307 @@
 // finalize rescales them.  Same lane mapping and reduction tree as normal_iid.hip.
 #include "bvi_common.h"
 
-template <int K, int CP>
-__global__ __launch_bounds__(256) void gmm1d_kernel(const float* __restrict__ y, int64_t n, int kreal,
-                                                    const float* __restrict__ theta, int C,
-                                                    float* __restrict__ partials) {
-  constexpr int RS = 64 / CP;
-  constexpr int Q = 1 + 3 * K;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cl = lane & (CP - 1), rsub = lane / CP;
-  const int chain = blockIdx.y * CP + cl;
-  const bool cvalid = chain < C;
-  float B[K], mu[K], isg[K];
-  {
-    const float* th = theta + (int64_t)(cvalid ? chain : 0) * 3 * kreal;
-    float wsum = 0.f;
-    for (int k = 0; k < kreal; ++k) wsum += th[k];
-    const float lw = __log2f(wsum);
+// Per chain: component means, scaled inverse widths and log2 heights relative to the tallest component
+// (hmax = max_k B_k, so every exponent below is <= 0 and no per-row maximum is needed).
+template <int K>
+struct MixParams {
+  float mu[K], isg[K], Bp[K];
+  float hmax;
+};
+
+template <int K>
+__device__ __forceinline__ void mix_load_params(const float* __restrict__ th, int kreal, MixParams<K>& p) {
+  float wsum = 0.f;
+  for (int k = 0; k < kreal; ++k) wsum += th[k];
+  const float lw = __log2f(wsum);
+  float B[K];
+  p.hmax = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (k < kreal) {
-        const float w = th[k], sc = th[2 * kreal + k];
-        mu[k] = th[kreal + k];
-        B[k] = __log2f(w) - lw - __log2f(sc) - 0.5f * BVI_LN2PI * BVI_LOG2E;
-        isg[k] = 0.84932180028801904f / sc;  // sqrt(log2(e)/2)
-      } else {
-        mu[k] = 0.f;
-        B[k] = -INFINITY;
-        isg[k] = 0.f;
-      }
+  for (int k = 0; k < K; ++k) {
+    if (k < kreal) {
+      const float w = th[k], sc = th[2 * kreal + k];
+      p.mu[k] = th[kreal + k];
+      B[k] = __log2f(w) - lw - __log2f(sc) - 0.5f * BVI_LN2PI * BVI_LOG2E;
+      p.isg[k] = 0.84932180028801904f / sc;  // sqrt(log2(e)/2)
+      p.hmax = fmaxf(p.hmax, B[k]);
+    } else {
+      p.mu[k] = 0.f;
+      B[k] = -INFINITY;
+      p.isg[k] = 0.f;
     }
   }
-  float tot[Q];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) tot[q] = 0.f;
+  for (int k = 0; k < K; ++k) p.Bp[k] = B[k] - p.hmax;
+}
 
-  const int64_t ntiles = (n + 63) / 64;
-  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
-    const int64_t i = t * 64 + lane;
-    const float yv = i < n ? y[i] : 0.f;
-    const bool full = t * 64 + 64 <= n;
-    float acc[Q];
+// One row with the per-row maximum subtracted before the exponentials: the form that cannot underflow,
+// taken only by rows that lie far from every component (mix_row sends them here).
+template <int K, bool GRAD>
+__device__ __forceinline__ void mix_row_far(float yj, float keep, const MixParams<K>& p, float (&acc)[1 + 3 * K]) {
+  float u[K], a[K];
+  float m = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < CP; ++j) {
-      const int src = rsub + RS * j;
-      const float yj = __shfl(yv, src, 64);
-      const float keep = (full || t * 64 + src < n) ? 1.f : 0.f;
-      float u[K], a[K];
-      float m = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    u[k] = (yj - p.mu[k]) * p.isg[k];
+    a[k] = fmaf(-u[k], u[k], p.Bp[k]);
+    m = fmaxf(m, a[k]);
+  }
+  float ssum = 0.f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        u[k] = (yj - mu[k]) * isg[k];
-        a[k] = fmaf(-u[k], u[k], B[k]);
-        m = fmaxf(m, a[k]);
-      }
-      float ssum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    a[k] = __builtin_amdgcn_exp2f(a[k] - m);
+    ssum += a[k];
+  }
+  acc[0] += keep * (m + __builtin_amdgcn_logf(ssum));
+  if (GRAD) {
+    const float inv = keep * __builtin_amdgcn_rcpf(ssum);
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        a[k] = __builtin_amdgcn_exp2f(a[k] - m);
-        ssum += a[k];
-      }
-      acc[0] += keep * (m + __builtin_amdgcn_logf(ssum));
-      const float inv = keep * __builtin_amdgcn_rcpf(ssum);
+    for (int k = 0; k < K; ++k) {
+      const float rho = a[k] * inv;
+      const float ru = rho * u[k];
+      acc[1 + k] += rho;
+      acc[1 + K + k] += ru;
+      acc[1 + 2 * K + k] = fmaf(ru, u[k], acc[1 + 2 * K + k]);
+    }
+  }
+}
+
+#ifndef BVI_GMM_NEAR_LOG2
+#define BVI_GMM_NEAR_LOG2 8
+#endif
+#ifndef BVI_GMM_SKIP_LOG2
+#define BVI_GMM_SKIP_LOG2 40
+#endif
+static constexpr float kMixNear = 1.f / (float)(1ull << BVI_GMM_NEAR_LOG2);
+static constexpr float kMixSkip = (float)BVI_GMM_SKIP_LOG2;
+static constexpr int kMixMaxBins = 512;
+#ifndef BVI_GMM_UNROLL
+#define BVI_GMM_UNROLL 1
+#endif
+#define BVI_PRAGMA_(x) _Pragma(#x)
+#define BVI_PRAGMA(x) BVI_PRAGMA_(x)
+
+// One row for the chain(s) of this lane.  Exponents are taken relative to the tallest component, so a row costs
+// (sub, mul, fma, exp2, add) per component and one log2; rows whose sum falls below 2^-8 of the tallest peak
+// (about 3.3 widths from the nearest component) are redone by mix_row_far.  With SKIP, only the components whose
+// bit is set in `act` (wave-uniform, see MixTable) are evaluated at all: a component left out has an exponent
+// below -40 in every lane of the wave, so what it would add is below 2^-32 of the sum that is kept.
+template <int K, bool GRAD, bool SKIP>
+__device__ __forceinline__ void mix_row(float yj, float keep, unsigned act, const MixParams<K>& p,
+                                        float (&acc)[1 + 3 * K]) {
+  float u[K], e[K];
+  if (SKIP) {   // u[k], e[k] are read only where they were set; an opaque definition spares the merges a copy each
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float rho = a[k] * inv;
+    for (int k = 0; k < K; ++k) {
+      asm volatile("" : "=v"(e[k]));
+      asm volatile("" : "=v"(u[k]));
+    }
+  }
+  float ssum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (!SKIP || (act & (1u << k))) {
+      if (SKIP) asm volatile("" ::);   // keeps the branch a branch: the body is not worth speculating
+      u[k] = (yj - p.mu[k]) * p.isg[k];
+      e[k] = __builtin_amdgcn_exp2f(fmaf(-u[k], u[k], p.Bp[k]));
+      ssum += e[k];
+    }
+  }
+  const bool near = ssum >= kMixNear;   // false for NaN as well: mix_row_far then produces the NaN
+  acc[0] += near ? keep * __builtin_amdgcn_logf(ssum) : 0.f;
+  if (GRAD) {
+    const float inv = near ? keep * __builtin_amdgcn_rcpf(ssum) : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!SKIP || (act & (1u << k))) {
+        if (SKIP) asm volatile("" ::);
+        const float rho = e[k] * inv;
         const float ru = rho * u[k];
         acc[1 + k] += rho;
         acc[1 + K + k] += ru;
         acc[1 + 2 * K + k] = fmaf(ru, u[k], acc[1 + 2 * K + k]);
       }
     }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) tot[q] += acc[q];
   }
+  if (__builtin_expect(!near, 0)) mix_row_far<K, GRAD>(yj, keep, p, acc);
+}
 
-  __shared__ float sm[4][CP][Q];
+// Which components can matter at a given y, for the chains of one wave: the y axis between the outermost reaches
+// of the wave's components is cut into `nbins` bins, and tab[1 + b] holds a bit per component that is set unless,
+// for every chain of the wave, the whole bin (widened by a bin on each side, which covers the rounding of the bin
+// index) lies where the component's exponent is below -kMixSkip.  tab[0] and tab[nbins + 1] (y outside every
+// reach) are 0: such rows take mix_row_far.  Non-finite parameters compare false and leave the bit set.
+template <int K>
+struct MixTable {
+  float y0, scale;
+  int nbins;
+  __device__ __forceinline__ void build(const MixParams<K>& p, int kreal, int nb, unsigned short* tab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    nbins = nb;
+    float lo[K], hi[K];
+    float ymin = INFINITY, ymax = -INFINITY;
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const float v = bvi_reduce_over_rowsubs<CP>(tot[q]);
-    if (rsub == 0) sm[wave][cl][q] = v;
+    for (int k = 0; k < K; ++k) {
+      if (k < kreal) {
+        const float reach = sqrtf(fmaxf(kMixSkip + p.Bp[k], 0.f)) / p.isg[k] * 1.0001f;
+        lo[k] = p.mu[k] - reach;
+        hi[k] = p.mu[k] + reach;
+        ymin = fminf(ymin, lo[k]);
+        ymax = fmaxf(ymax, hi[k]);
+      } else {
+        lo[k] = INFINITY;
+        hi[k] = -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      ymin = fminf(ymin, __shfl_xor(ymin, off, 64));
+      ymax = fmaxf(ymax, __shfl_xor(ymax, off, 64));
+    }
+    y0 = ymin;
+    const float width = fmaxf(ymax - ymin, 1e-30f) / (float)nb;
+    scale = 1.f / width;
+    for (int b = wave; b < nb; b += 4) {
+      const float blo = y0 + (float)(b - 1) * width, bhi = y0 + (float)(b + 2) * width;
+      unsigned m = 0;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        m |= (__builtin_amdgcn_ballot_w64(!(hi[k] < blo || lo[k] > bhi)) != 0 ? 1u : 0u) << k;
+      if (lane == 0) tab[1 + b] = (unsigned short)m;
+    }
+    if (threadIdx.x == 0) tab[0] = tab[nb + 1] = 0u;
   }
-  __syncthreads();
-  // raw layout per chain: [L2, A0[kreal], A1[kreal], A2[kreal]]
-  const int qreal = 1 + 3 * kreal;
-  for (int idx = threadIdx.x; idx < CP * qreal; idx += 256) {
-    const int c = idx / qreal, q = idx - c * qreal;
-    const int gc = blockIdx.y * CP + c;
-    if (gc >= C) continue;
+  // table entry for the row each lane holds (NaN rows read entry 0 and come out NaN through mix_row_far)
+  __device__ __forceinline__ unsigned lookup(float yv, const unsigned short* tab) const {
+    const float fb = fminf(fmaxf(floorf((yv - y0) * scale), -1.f), (float)nbins);
+    return tab[(int)fb + 1];
+  }
+};
+
+// raw layout per chain in the partials: [L2, A0[kreal], A1[kreal], A2[kreal]]; a value-only launch writes L2 only.
+// red[q][64 * wave + c] holds wave `wave`'s sum q for the c-th chain of the block.
+template <int K, int NC, bool GRAD>
+__device__ __forceinline__ void mix_store_partials(const float (*red)[256], int kreal, int c0, int C,
+                                                   float* __restrict__ partials) {
+  const int qreal = 1 + 3 * kreal, qw = GRAD ? qreal : 1;
+  for (int idx = threadIdx.x; idx < NC * qw; idx += 256) {
+    const int c = idx / qw, q = idx - c * qw;
+    if (c0 + c >= C) continue;
     int qs = 0;
     if (q > 0) {
       const int part = (q - 1) / kreal, k = (q - 1) - part * kreal;
       qs = 1 + part * K + k;
     }
-    const float v = sm[0][c][qs] + sm[1][c][qs] + sm[2][c][qs] + sm[3][c][qs];
-    partials[((int64_t)blockIdx.x * C + gc) * qreal + q] = v;
+    partials[((int64_t)blockIdx.x * C + c0 + c) * qreal + q] =
+        (red[qs][c] + red[qs][64 + c]) + (red[qs][128 + c] + red[qs][192 + c]);
   }
+}
+
+#ifndef BVI_GMM_WAVES
+#define BVI_GMM_WAVES 6
+#endif
+template <int K, int CP, bool GRAD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? BVI_GMM_WAVES : 3)))
+void gmm1d_kernel(const float* __restrict__ y, int64_t n, int kreal,
+                                                    const float* __restrict__ theta, int C, int nbins,
+                                                    float* __restrict__ partials) {
+  constexpr int RS = 64 / CP;
+  constexpr int Q = 1 + 3 * K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = lane & (CP - 1), rsub = lane / CP;
+  const int chain = blockIdx.y * CP + cl;
+  MixParams<K> p;
+  mix_load_params<K>(theta + (int64_t)(chain < C ? chain : 0) * 3 * kreal, kreal, p);
+  __shared__ unsigned short tab[kMixMaxBins + 2];
+  MixTable<K> table;
+  if (nbins > 0) {   // all four waves hold the same chains, so one table serves the block
+    table.build(p, kreal, nbins, tab);
+    __syncthreads();
+  }
+  // Sums over this lane's rows are kept at two levels (per tile in registers, per kernel below) so that no float
+  // accumulates more than a few hundred addends; the kernel-level gradient sums live in LDS, one column per
+  // thread, which leaves registers for six waves per SIMD (the row loop is a chain of short scalar branches and
+  // needs the other waves to fill its issue slots).
+  __shared__ float red[GRAD ? Q : 1][256];
+  if (GRAD) {
+#pragma unroll
+    for (int q = 1; q < Q; ++q) red[q][threadIdx.x] = 0.f;
+  }
+  float tot0 = 0.f;
+  float rows = 0.f;   // rows this lane has added to tot0, each relative to hmax
+
+  const int64_t ntiles = (n + 63) / 64, tstep = (int64_t)gridDim.x * 4;
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  float ynext = (t < ntiles && t * 64 + lane < n) ? y[t * 64 + lane] : 0.f;
+  for (; t < ntiles; t += tstep) {
+    const float yv = ynext;
+    const int64_t inext = (t + tstep) * 64 + lane;
+    ynext = inext < n ? y[inext] : 0.f;   // rows of the next tile are in flight while this one is evaluated
+    const unsigned maskv = nbins > 0 ? table.lookup(yv, tab) : (1u << K) - 1u;
+    float acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = 0.f;
+    auto row = [&](int j, float keep) {
+      // rows RS*j .. RS*j+RS-1 of the tile are evaluated together, one per row subset of the wave
+      unsigned act = 0;
+#pragma unroll
+      for (int r = 0; r < RS; ++r) act |= (unsigned)__builtin_amdgcn_readlane((int)maskv, RS * j + r);
+      const float yj = CP == 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yv), j))
+                                : __shfl(yv, rsub + RS * j, 64);
+      mix_row<K, GRAD, true>(yj, keep, act, p, acc);
+    };
+    if (t * 64 + 64 <= n) {
+      BVI_PRAGMA(unroll BVI_GMM_UNROLL)
+      for (int j = 0; j < CP; ++j) row(j, 1.f);
+      rows += (float)CP;
+    } else {
+      for (int j = 0; j < CP; ++j) {
+        const float keep = t * 64 + rsub + RS * j < n ? 1.f : 0.f;
+        row(j, keep);
+        rows += keep;
+      }
+    }
+    tot0 += acc[0];
+    if (GRAD) {
+#pragma unroll
+      for (int q = 1; q < Q; ++q) red[q][threadIdx.x] += acc[q];
+    }
+  }
+  tot0 = fmaf(rows, p.hmax, tot0);
+
+  red[0][threadIdx.x] = tot0;
+  if (CP < 64) {   // add the row subsets of a wave into its first CP lanes (each thread rewrites its own column)
+#pragma unroll
+    for (int q = 0; q < (GRAD ? Q : 1); ++q) red[q][threadIdx.x] = bvi_reduce_over_rowsubs<CP>(red[q][threadIdx.x]);
+  }
+  __syncthreads();
+  mix_store_partials<K, CP, GRAD>(red, kreal, blockIdx.y * CP, C, partials);
 }
 
 // Few chains per group (CG = 1 or 4): every lane streams rows of its own with 16-byte loads and carries the
 // sums of all CG chains in registers; the chains' parameters are wave-uniform (scalar registers).  The shuffle
 // mapping above issues one 4-byte load per lane and iteration, which leaves too little in flight when the
-// per-row work is small (one or a few chains).
-template <int K, int CG>
+// per-row work is small (one or a few chains).  Lanes hold different rows here, so no component is skipped.
+template <int K, int CG, bool GRAD>
 __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict__ y, int64_t n, int kreal,
                                                          const float* __restrict__ theta, int C,
                                                          float* __restrict__ partials) {
   constexpr int Q = 1 + 3 * K;
   const int c0 = blockIdx.y * CG;
-  float B[CG][K], mu[CG][K], isg[CG][K];
+  MixParams<K> p[CG];
 #pragma unroll
-  for (int g = 0; g < CG; ++g) {
-    const float* th = theta + (int64_t)(c0 + g < C ? c0 + g : 0) * 3 * kreal;   // padding chains: results dropped
-    float wsum = 0.f;
-    for (int k = 0; k < kreal; ++k) wsum += th[k];
-    const float lw = __log2f(wsum);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (k < kreal) {
-        const float w = th[k], sc = th[2 * kreal + k];
-        mu[g][k] = th[kreal + k];
-        B[g][k] = __log2f(w) - lw - __log2f(sc) - 0.5f * BVI_LN2PI * BVI_LOG2E;
-        isg[g][k] = 0.84932180028801904f / sc;  // sqrt(log2(e)/2)
-      } else {
-        mu[g][k] = 0.f;
-        B[g][k] = -INFINITY;
-        isg[g][k] = 0.f;
-      }
-    }
-  }
+  for (int g = 0; g < CG; ++g)   // padding chains: results dropped
+    mix_load_params<K>(theta + (int64_t)(c0 + g < C ? c0 + g : 0) * 3 * kreal, kreal, p[g]);
   float acc[CG][Q];
 #pragma unroll
   for (int g = 0; g < CG; ++g)
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[g][q] = 0.f;
+  float rows = 0.f;
   auto row = [&](float yj) {
 #pragma unroll
-    for (int g = 0; g < CG; ++g) {
-      float u[K], a[K];
-      float m = -INFINITY;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        u[k] = (yj - mu[g][k]) * isg[g][k];
-        a[k] = fmaf(-u[k], u[k], B[g][k]);
-        m = fmaxf(m, a[k]);
-      }
-      float ssum = 0.f;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        a[k] = __builtin_amdgcn_exp2f(a[k] - m);
-        ssum += a[k];
-      }
-      acc[g][0] += m + __builtin_amdgcn_logf(ssum);
-      const float inv = __builtin_amdgcn_rcpf(ssum);
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float rho = a[k] * inv;
-        const float ru = rho * u[k];
-        acc[g][1 + k] += rho;
-        acc[g][1 + K + k] += ru;
-        acc[g][1 + 2 * K + k] = fmaf(ru, u[k], acc[g][1 + 2 * K + k]);
-      }
-    }
+    for (int g = 0; g < CG; ++g) mix_row<K, GRAD, false>(yj, 1.f, 0u, p[g], acc[g]);
+    rows += 1.f;
   };
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   int64_t head = (int64_t)(((16 - ((uintptr_t)y & 15)) & 15) >> 2);
@@ -196,30 +334,20 @@ __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict
   }
   if (tid < head) row(y[tid]);
   if (tid < n - tail0) row(y[tail0 + tid]);
+#pragma unroll
+  for (int g = 0; g < CG; ++g) acc[g][0] = fmaf(rows, p[g].hmax, acc[g][0]);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ float sm[4][CG][Q];
+  __shared__ float red[GRAD ? Q : 1][256];
 #pragma unroll
   for (int g = 0; g < CG; ++g)
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
+    for (int q = 0; q < (GRAD ? Q : 1); ++q) {
       const float v = bvi_reduce_over_rowsubs<1>(acc[g][q]);
-      if (lane == 0) sm[wave][g][q] = v;
+      if (lane == 0) red[q][64 * wave + g] = v;
     }
   __syncthreads();
-  // raw layout per chain: [L2, A0[kreal], A1[kreal], A2[kreal]]
-  const int qreal = 1 + 3 * kreal;
-  for (int idx = threadIdx.x; idx < CG * qreal; idx += 256) {
-    const int g = idx / qreal, q = idx - g * qreal;
-    if (c0 + g >= C) continue;
-    int qs = 0;
-    if (q > 0) {
-      const int part = (q - 1) / kreal, k = (q - 1) - part * kreal;
-      qs = 1 + part * K + k;
-    }
-    partials[((int64_t)blockIdx.x * C + c0 + g) * qreal + q] =
-        (sm[0][g][qs] + sm[1][g][qs]) + (sm[2][g][qs] + sm[3][g][qs]);
-  }
+  mix_store_partials<K, CG, GRAD>(red, kreal, c0, C, partials);
 }
 
 // one thread (WAVE = false) or one wave (WAVE = true) per gradient entry
@@ -232,10 +360,11 @@ __global__ void gmm1d_finalize(const float* __restrict__ partials, int nb, int64
   if (idx >= C * q3) return;
   const int c = idx / q3, j = idx - c * q3;  // j indexes the gradient entry (w | mu | scale)
   const int part = j / k, kk = j - part * k;
+  if (!grad && j != 0) return;   // a value-only launch wrote L2 only
   const float* th = theta + (int64_t)c * q3;
   const float* pc = partials + (int64_t)c * qreal;
   const int64_t stride = (int64_t)C * qreal;
-  const double a0 = bvi_sum_partials<WAVE>(pc + 1 + kk, nb, stride);
+  const double a0 = grad ? bvi_sum_partials<WAVE>(pc + 1 + kk, nb, stride) : 0.0;
   double ax = 0.0, l2 = 0.0;
   if (part == 1) ax = bvi_sum_partials<WAVE>(pc + 1 + k + kk, nb, stride);
   if (part == 2) ax = bvi_sum_partials<WAVE>(pc + 1 + 2 * k + kk, nb, stride);
@@ -266,18 +395,31 @@ size_t bvi_ws_gmm1d(int64_t n, int c, int k) {
   return (size_t)gmm1d_blocks(n) * c * (1 + 3 * k) * sizeof(float);
 }
 
-template <int K>
+template <int K, bool GRAD>
 static void gmm1d_dispatch_cp(int cp, dim3 grid, hipStream_t s, const float* y, int64_t n, int k,
                               const float* theta, int c, float* ws) {
+  // bins of the component table: building it costs a block ~8 instructions per bin and component, so it is sized
+  // to the rows a block streams (none at all for short inputs: every component is then evaluated)
+  const int64_t rows_per_block = n / grid.x;
+  const int nbins = rows_per_block >= 16384 ? kMixMaxBins : rows_per_block >= 2048 ? 128 : 0;
   switch (cp) {
-    case 1: hipLaunchKernelGGL((gmm1d_rows_kernel<K, 1>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
+    case 1: hipLaunchKernelGGL((gmm1d_rows_kernel<K, 1, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
     case 4:
-      if (K <= 8) hipLaunchKernelGGL((gmm1d_rows_kernel<K <= 8 ? K : 8, 4>), grid, dim3(256), 0, s, y, n, k, theta, c, ws);
-      else hipLaunchKernelGGL((gmm1d_kernel<K, 4>), grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+      if (K <= 8) hipLaunchKernelGGL((gmm1d_rows_kernel<K <= 8 ? K : 8, 4, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+      else hipLaunchKernelGGL((gmm1d_kernel<K, 4, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws);
       break;
-    case 16: hipLaunchKernelGGL((gmm1d_kernel<K, 16>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
-    default: hipLaunchKernelGGL((gmm1d_kernel<K, 64>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
+    case 16: hipLaunchKernelGGL((gmm1d_kernel<K, 16, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws); break;
+    default: hipLaunchKernelGGL((gmm1d_kernel<K, 64, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws); break;
   }
+}
+
+template <bool GRAD>
+static void gmm1d_dispatch_k(int cp, dim3 grid, hipStream_t s, const float* y, int64_t n, int k, const float* theta,
+                             int c, float* ws) {
+  if (k <= 2) gmm1d_dispatch_cp<2, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
+  else if (k <= 4) gmm1d_dispatch_cp<4, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
+  else if (k <= 8) gmm1d_dispatch_cp<8, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
+  else gmm1d_dispatch_cp<16, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
 }
 
 int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c, float* logp, float* grad,
@@ -286,10 +428,8 @@ int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c
   const int nb = gmm1d_blocks(n);
   const int cp = bvi_chain_pack(c);
   dim3 grid(nb, bvi_ceil_div(c, cp));
-  if (k <= 2) gmm1d_dispatch_cp<2>(cp, grid, s, y, n, k, theta, c, ws);
-  else if (k <= 4) gmm1d_dispatch_cp<4>(cp, grid, s, y, n, k, theta, c, ws);
-  else if (k <= 8) gmm1d_dispatch_cp<8>(cp, grid, s, y, n, k, theta, c, ws);
-  else gmm1d_dispatch_cp<16>(cp, grid, s, y, n, k, theta, c, ws);
+  if (grad) gmm1d_dispatch_k<true>(cp, grid, s, y, n, k, theta, c, ws);
+  else gmm1d_dispatch_k<false>(cp, grid, s, y, n, k, theta, c, ws);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * 3 * k;
   if (nb > 32)

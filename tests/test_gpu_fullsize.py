@@ -152,6 +152,72 @@ def test_regression_10m_rescaling_property(nat, ws, regression_10m):
            what='grad rescaled')
 
 
+def _mixture_float64(y, th, k):
+    """Chunked float64 evaluation of the 1-D mixture on the device: log density, gradient and the sum of
+    absolute per-row gradient terms (the scale rounding errors are measured against) for a few chains."""
+    n, dev = y.shape[0], y.device
+    t2 = th.double(); c = t2.shape[0]
+    wgt, mu, sc = t2[:, :k], t2[:, k:2 * k], t2[:, 2 * k:]
+    ref_lp = torch.zeros(c, dtype=torch.float64, device=dev)
+    ref_g = torch.zeros(c, 3 * k, dtype=torch.float64, device=dev)
+    absg = torch.zeros(c, 3 * k, dtype=torch.float64, device=dev)
+    logw = torch.log(wgt / wgt.sum(-1, keepdim=True))
+    step = max(1, (1 << 25) // (c * k))
+    for s in range(0, n, step):
+        yc = y[s:s + step].double()[None, :, None]
+        u = (yc - mu[:, None]) / sc[:, None]
+        e = logw[:, None] - torch.log(sc[:, None]) - 0.5 * math.log(2 * math.pi) - 0.5 * u * u
+        lse = torch.logsumexp(e, -1)
+        rho = torch.exp(e - lse[..., None])
+        ref_lp += lse.sum(-1)
+        parts = [rho / wgt[:, None] - 1.0 / wgt.sum(-1)[:, None, None], rho * u / sc[:, None],
+                 rho * (u * u - 1) / sc[:, None]]
+        ref_g += torch.cat([p.sum(1) for p in parts], -1)
+        absg += torch.cat([p.abs().sum(1) for p in parts], -1)
+    return ref_lp, ref_g, absg
+
+
+@pytest.mark.parametrize('n', [3_000_001, 20_000_003])
+@pytest.mark.parametrize('case', ['separated', 'overlapping', 'k3', 'k16'])
+def test_mixture_component_table(nat, ws, gpu_device, n, case):
+    """Inputs long enough for the kernel to build its table of the components that matter at each y (128 bins at
+    3M rows, 1024 at 20M): separated and heavily overlapping components, very unequal weights, K below and at
+    the template sizes, rows far outside every component (the per-row-maximum path), one chain with a NaN mean.
+    Chains 0-2 and the last one against float64; the value-only launch returns the same log densities."""
+    g = torch.Generator(device=gpu_device); g.manual_seed(11)
+    k = {'separated': 8, 'overlapping': 6, 'k3': 3, 'k16': 16}[case]
+    c = 64 if case != 'k16' else 9          # 9 chains of K = 16: the 16-chain shuffle mapping
+    if case == 'overlapping':
+        locs = torch.linspace(-2, 2, k, device=gpu_device)
+        wbase = torch.tensor([0.01, 0.6, 0.05, 0.2, 0.04, 0.1], device=gpu_device)
+        sbase = torch.tensor([0.2, 1.0, 5.0, 0.5, 2.0, 0.3], device=gpu_device)
+    else:
+        locs = torch.linspace(-20, 20, k, device=gpu_device)
+        wbase = torch.full((k,), 1.0 / k, device=gpu_device)
+        sbase = torch.ones(k, device=gpu_device)
+    comp = torch.multinomial(wbase, n, replacement=True, generator=g)
+    y = locs[comp] + sbase[comp] * torch.randn(n, generator=g, device=gpu_device)
+    del comp
+    y[::100_003] = 1000.0            # rows no component reaches
+    y[7::250_007] = -37.5
+    y[11::300_017] = 2.857           # between two of the separated components
+    th = torch.cat([wbase * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device)),
+                    locs + 0.1 * torch.randn(c, k, generator=g, device=gpu_device),
+                    sbase * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device))], -1).contiguous()
+    th[c - 1, k:2 * k] += 3.0        # one chain far from the others: its components widen the wave's table entries
+    lp, gr = nat.gmm1d_logp_grad(y, th, k, ws)
+    lpv, _ = nat.gmm1d_logp_grad(y, th, k, ws, want_grad=False)
+    assert torch.equal(lp, lpv)
+    sel = torch.tensor([0, 1, 2, c - 1], device=gpu_device)
+    ref_lp, ref_g, absg = _mixture_float64(y, th[sel], k)
+    _close(lp[sel], ref_lp, ref_lp.abs(), what='mixture logp (%s)' % case)
+    _close(gr[sel], ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg, what='mixture grad (%s)' % case)
+    bad = th.clone(); bad[1, k + 1] = float('nan')
+    lpb, grb = nat.gmm1d_logp_grad(y, bad, k, ws)
+    assert bool(torch.isnan(lpb[1])) and bool(torch.isfinite(lpb[[0, 2]]).all())
+    assert torch.equal(lpb[[0, 2, c - 1]], lp[[0, 2, c - 1]])
+
+
 def test_mixture_100m_rows(nat, ws, gpu_device):
     """BASELINE.json configs[2] size: K = 8 mixture over 100M rows.  Row shards (cut at an odd row, so the
     second shard is not 16-byte aligned) add up; two chains against a chunked float64 evaluation."""
@@ -170,24 +236,7 @@ def test_mixture_100m_rows(nat, ws, gpu_device):
     cut = 41_234_567
     a = nat.gmm1d_logp_grad(y[:cut], th, k, ws)
     b = nat.gmm1d_logp_grad(y[cut:], th, k, ws)
-    # float64 reference for two chains, chunked
-    t2 = th[:2].double()
-    wgt, mu, sc = t2[:, :k], t2[:, k:2 * k], t2[:, 2 * k:]
-    ref_lp = torch.zeros(2, dtype=torch.float64, device=gpu_device)
-    ref_g = torch.zeros(2, 3 * k, dtype=torch.float64, device=gpu_device)
-    absg = torch.zeros(2, 3 * k, dtype=torch.float64, device=gpu_device)
-    logw = torch.log(wgt / wgt.sum(-1, keepdim=True))
-    for s in range(0, n, 1 << 22):
-        yc = y[s:s + (1 << 22)].double()[None, :, None]
-        u = (yc - mu[:, None]) / sc[:, None]
-        e = logw[:, None] - torch.log(sc[:, None]) - 0.5 * math.log(2 * math.pi) - 0.5 * u * u
-        lse = torch.logsumexp(e, -1)
-        rho = torch.exp(e - lse[..., None])
-        ref_lp += lse.sum(-1)
-        parts = [rho / wgt[:, None] - 1.0 / wgt.sum(-1)[:, None, None], rho * u / sc[:, None],
-                 rho * (u * u - 1) / sc[:, None]]
-        ref_g += torch.cat([p.sum(1) for p in parts], -1)
-        absg += torch.cat([p.abs().sum(1) for p in parts], -1)
+    ref_lp, ref_g, absg = _mixture_float64(y, th[:2], k)
     _close(lp[:2], ref_lp, ref_lp.abs(), what='mixture logp')
     _close(gr[:2], ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg, what='mixture grad')
     _close(a[0].double() + b[0].double(), lp, lp.abs(), what='mixture logp shards')
