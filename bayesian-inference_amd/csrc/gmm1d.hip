@@ -125,9 +125,13 @@ __device__ __forceinline__ void mix_row(float yj, float keep, unsigned act, cons
   acc[0] += near ? keep * __builtin_amdgcn_logf(ssum) : 0.f;
   if (GRAD) {
     const float inv = near ? keep * __builtin_amdgcn_rcpf(ssum) : 0.f;
+    // a copy the compiler cannot relate to `act`: it then tests one bit per component here as above instead of
+    // carrying eight 64-bit lane masks from the first pass to this one
+    unsigned act2 = act;
+    if (SKIP) asm volatile("" : "+s"(act2));
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      if (!SKIP || (act & (1u << k))) {
+      if (!SKIP || (act2 & (1u << k))) {
         if (SKIP) asm volatile("" ::);
         const float rho = e[k] * inv;
         const float ru = rho * u[k];
