@@ -269,12 +269,17 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/, same
     # command, full 10M-row shard only); null when the run is not that configuration
     traffic = None
+    traffic_source = None
     try:
         if uses_mfma16 and n_local == 10_000_000 and c == 1024 and d == 64:
-            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as f:
-                for k, v in json.load(f)['kernels'].items():
-                    if kernel_name in k:
-                        traffic = v.get('hbm_bytes_per_launch_corrected')
+            import glob
+            # newest summary first (profiles/r<round>_pmc_traffic.json); the first that measured this kernel wins
+            for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+                with open(path) as f:
+                    for k, v in json.load(f)['kernels'].items():
+                        if kernel_name in k and traffic is None:
+                            traffic = v.get('hbm_bytes_per_launch_corrected')
+                            traffic_source = os.path.basename(path)
     except (OSError, ValueError, KeyError):
         traffic = None
     out = {
@@ -296,7 +301,7 @@ def main():
                    'parallelism': 'rows sharded over %d GPU(s), chains replicated, all-reduce of [C,1+P] per step' % world},
         'roofline': {
             'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-            'traffic': traffic,
+            'traffic': traffic, 'traffic_source': traffic_source,
             'kernel': kernel_name,
             'kernel_ms': kern_ms, 'algorithmic_flops_per_launch': flops,
             'hbm': {'algorithmic_bytes_per_launch': alg_bytes, 'achieved_GBps': alg_bytes / (kern_ms * 1e-3) / 1e9,

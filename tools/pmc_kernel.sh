@@ -11,7 +11,7 @@ import csv, glob, os, sys, collections
 f = glob.glob(sys.argv[1] + '/p/**/*counter_collection.csv', recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    if os.environ.get('PMC_KERNEL', 'linreg_f16_kernel') in r['Kernel_Name']:
+    if os.environ.get('PMC_KERNEL', 'linreg_f16_pipe_kernel') in r['Kernel_Name']:
         acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 import json
 out = {}

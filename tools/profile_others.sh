@@ -18,4 +18,5 @@ run config0 tools/config0_bench.py
 run vi_cfg5 tools/vi_bench.py
 run mixture tools/gmm_bench.py
 run fullcov tools/fullcov_bench.py
+run config3_nuts tools/config3_nuts_bench.py
 ls "$OUT"
