@@ -20,7 +20,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 102     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 103     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -71,16 +71,17 @@ def lib():
         l.bvi_status_string.restype = ctypes.c_char_p
         l.bvi_status_string.argtypes = [i32]
         l.bvi_workspace_bytes.argtypes = [i32, i64, i32, i32, i32, ctypes.POINTER(sz)]
-        l.bvi_normal_iid_logp_grad.argtypes = [vp, i64, vp, i32, vp, vp, vp, sz, vp]
-        l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, sz, vp]
+        l.bvi_normal_iid_logp_grad.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_linreg_logp_grad.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_normal_iid_logp_grad_noalloc.argtypes = [vp, i64, vp, i32, vp, vp, vp]
         l.bvi_normal_iid_logp_grad_noalloc.restype = i32
-        l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, sz, vp]
-        l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, sz, vp]
+        l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_logp_rebase.argtypes = [i32, vp, i32, vp, vp, vp]
         l.bvi_linreg_packed_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]
         l.bvi_linreg_pack_scratch_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
         l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, i32, vp, sz, vp, sz, vp]
-        l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, i32, vp, vp, vp, sz, vp]
+        l.bvi_linreg_packed_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp, sz, vp]
         bp, u64, f32 = ctypes.POINTER(ParamBlock), ctypes.c_uint64, ctypes.c_float
         l.bvi_constrain.argtypes = [bp, i32, i32, vp, vp, vp]
         l.bvi_posterior_assemble.argtypes = [bp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -111,7 +112,7 @@ def lib():
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
-                     'bvi_linreg_packed_logp_grad'):
+                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase'):
             getattr(l, name).restype = i32
         _lib = l
     return _lib
@@ -159,6 +160,22 @@ class Workspace:
         return self.buf
 
 
+def _ref_ptr(logp_ref):
+    """Device address of the level the likelihood entry points subtract in double (one float64), or NULL."""
+    if logp_ref is None:
+        return None
+    if not (logp_ref.is_cuda and logp_ref.dtype == torch.float64 and logp_ref.numel() == 1):
+        raise BviError('logp_ref must be one float64 on the device')
+    return logp_ref.data_ptr()
+
+
+def logp_rebase(lp, n_shards, logp_ref, lp_absolute=None):
+    """bvi_logp_rebase: lp -= max finite lp; logp_ref += that / n_shards; lp_absolute <- the absolute values."""
+    _check_f32_cuda(lp)
+    check(lib().bvi_logp_rebase(lp.shape[0], _ptr(lp), int(n_shards), _ref_ptr(logp_ref), _ptr(lp_absolute), _stream()),
+          'bvi_logp_rebase')
+
+
 def _outputs(theta, want_grad):
     c = theta.shape[0]
     logp = torch.empty(c, dtype=torch.float32, device=theta.device)
@@ -166,18 +183,18 @@ def _outputs(theta, want_grad):
     return logp, grad
 
 
-def normal_iid_logp_grad(y, theta, ws: Workspace, want_grad=True):
+def normal_iid_logp_grad(y, theta, ws: Workspace, want_grad=True, logp_ref=None):
     _check_f32_cuda(y, theta)
     n, c = y.shape[0], theta.shape[0]
     assert theta.shape == (c, 2)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_NORMAL_IID, n, c))
-    check(lib().bvi_normal_iid_logp_grad(_ptr(y), n, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
-                                         buf.numel(), _stream()), 'bvi_normal_iid_logp_grad')
+    check(lib().bvi_normal_iid_logp_grad(_ptr(y), n, _ptr(theta), c, _ptr(logp), _ptr(grad), _ref_ptr(logp_ref),
+                                         _ptr(buf), buf.numel(), _stream()), 'bvi_normal_iid_logp_grad')
     return logp, grad
 
 
-def linreg_logp_grad(X, y, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO):
+def linreg_logp_grad(X, y, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO, logp_ref=None):
     _check_f32_cuda(X, y, theta)
     n, d = X.shape
     c = theta.shape[0]
@@ -185,18 +202,18 @@ def linreg_logp_grad(X, y, theta, ws: Workspace, want_grad=True, precision=PREC_
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_LINREG, n, c, d=d))
     check(lib().bvi_linreg_logp_grad(_ptr(X), _ptr(y), n, d, _ptr(theta), c, precision, _ptr(logp), _ptr(grad),
-                                     _ptr(buf), buf.numel(), _stream()), 'bvi_linreg_logp_grad')
+                                     _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()), 'bvi_linreg_logp_grad')
     return logp, grad
 
 
-def gmm1d_logp_grad(y, theta, k, ws: Workspace, want_grad=True):
+def gmm1d_logp_grad(y, theta, k, ws: Workspace, want_grad=True, logp_ref=None):
     _check_f32_cuda(y, theta)
     n, c = y.shape[0], theta.shape[0]
     assert theta.shape == (c, 3 * k)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_GMM1D, n, c, k=k))
-    check(lib().bvi_gmm1d_logp_grad(_ptr(y), n, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
-                                    buf.numel(), _stream()), 'bvi_gmm1d_logp_grad')
+    check(lib().bvi_gmm1d_logp_grad(_ptr(y), n, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ref_ptr(logp_ref),
+                                    _ptr(buf), buf.numel(), _stream()), 'bvi_gmm1d_logp_grad')
     return logp, grad
 
 
@@ -215,14 +232,14 @@ def linreg_pack(X, y, fmt=PACK_BF16X3):
 
 
 def linreg_packed_logp_grad(packed, n, d, theta, ws: Workspace, want_grad=True, precision=PREC_AUTO,
-                            fmt=PACK_BF16X3):
+                            fmt=PACK_BF16X3, logp_ref=None):
     _check_f32_cuda(theta)
     c = theta.shape[0]
     assert theta.shape == (c, d + 2)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_LINREG, n, c, d=d))
     check(lib().bvi_linreg_packed_logp_grad(_ptr(packed), n, d, fmt, _ptr(theta), c, precision, _ptr(logp),
-                                            _ptr(grad), _ptr(buf), buf.numel(), _stream()),
+                                            _ptr(grad), _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()),
           'bvi_linreg_packed_logp_grad')
     return logp, grad
 
@@ -251,13 +268,14 @@ def philox_normal(seed, step, n_chains, n_params, device):
     return out
 
 
-def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True):
+def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True, logp_ref=None):
     _check_f32_cuda(Y, theta)
     n, d = Y.shape
     c = theta.shape[0]
     assert theta.shape == (c, k + k * d + k * d * d)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_GMM_FULLCOV, n, c, d=d, k=k))
-    check(lib().bvi_gmm_fullcov_logp_grad(_ptr(Y), n, d, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ptr(buf),
-                                          buf.numel(), _stream()), 'bvi_gmm_fullcov_logp_grad')
+    check(lib().bvi_gmm_fullcov_logp_grad(_ptr(Y), n, d, k, _ptr(theta), c, _ptr(logp), _ptr(grad),
+                                          _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()),
+          'bvi_gmm_fullcov_logp_grad')
     return logp, grad

@@ -105,6 +105,13 @@ class FusedLogLikelihood(ShardedLogLikelihood):
             raise _native.BviError('the fused log-likelihood runs on MI355X only; got device %s' % device)
         _native.lib()
         self.ws = _native.Workspace(self.device)
+        # level (one float64 on the device) that the kernels subtract from every log-likelihood before rounding it
+        # to float; None = absolute values.  The samplers switch it on and keep it near the chains' current values
+        # (Posterior.rebase), so that the differences they decide on stay exact when |log-likelihood| ~ 1e7.
+        self.logp_ref = None
+
+    def _ref(self):
+        return None if self.logp_ref is None else self.logp_ref.data_ptr()
 
 
 def _launch(fn, *args):
@@ -125,7 +132,7 @@ class NormalIID(FusedLogLikelihood):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c))
         _launch(_native.lib().bvi_normal_iid_logp_grad, _native._ptr(self.y), self.n, _native._ptr(theta), c,
-                _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(), _native._stream())
+                _native._ptr(logp), _native._ptr(grad), self._ref(), _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class LinearRegression(FusedLogLikelihood):
@@ -180,12 +187,12 @@ class LinearRegression(FusedLogLikelihood):
                 self.packed = _native.linreg_pack(self.X, self.y, fmt=fmt)
                 self.packed_format = fmt
             _launch(_native.lib().bvi_linreg_packed_logp_grad, _native._ptr(self.packed), self.n, self.d,
-                    fmt, _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad),
+                    fmt, _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), self._ref(),
                     _native._ptr(buf), buf.numel(), _native._stream())
             return
         _launch(_native.lib().bvi_linreg_logp_grad, _native._ptr(self.X), _native._ptr(self.y), self.n, self.d,
-                _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), _native._ptr(buf),
-                buf.numel(), _native._stream())
+                _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), self._ref(),
+                _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class GaussianMixture1D(FusedLogLikelihood):
@@ -203,7 +210,7 @@ class GaussianMixture1D(FusedLogLikelihood):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, k=self.k))
         _launch(_native.lib().bvi_gmm1d_logp_grad, _native._ptr(self.y), self.n, self.k, _native._ptr(theta), c,
-                _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(), _native._stream())
+                _native._ptr(logp), _native._ptr(grad), self._ref(), _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class GaussianMixtureFullCov(FusedLogLikelihood):
@@ -222,8 +229,8 @@ class GaussianMixtureFullCov(FusedLogLikelihood):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d, k=self.k))
         _launch(_native.lib().bvi_gmm_fullcov_logp_grad, _native._ptr(self.Y), self.n, self.d, self.k,
-                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), _native._ptr(buf), buf.numel(),
-                _native._stream())
+                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(), _native._ptr(buf),
+                buf.numel(), _native._stream())
 
 
 class Posterior:
@@ -288,6 +295,58 @@ class Posterior:
             specs = None
         self._blocks = _native.make_blocks(specs) if specs is not None else None
         return self._blocks
+
+    # ---- log-densities relative to a level that follows the chains ----
+    # A float holds log pi ~ 1e7 (10M rows) to +-0.5, the size of the energy differences the samplers decide on.
+    # The device samplers therefore ask the likelihood kernels for values relative to a level kept on the device
+    # (one float64; bvi_logp_rebase moves it to the chains' best current value after every transition), so what is
+    # stored and subtracted stays small and exact; target_log_prob is reported absolute, as the reference does.
+    def use_relative_log_prob(self):
+        lik = self.likelihood
+        if hasattr(lik, 'logp_ref') and lik.logp_ref is None and lik.device.type == 'cuda':
+            lik.logp_ref = torch.zeros(1, dtype=torch.float64, device=lik.device)
+        return getattr(lik, 'logp_ref', None) is not None
+
+    def _shards(self):
+        lik = self.likelihood
+        return dist.get_world_size(lik.group) if lik.sharded else 1
+
+    def rebase(self, lp, lp_absolute=None):
+        """After a transition: re-level the chains' stored log-densities `lp` in place (no-op without a level);
+        lp_absolute, if given, receives their absolute values."""
+        ref = getattr(self.likelihood, 'logp_ref', None)
+        if ref is None:
+            if lp_absolute is not None:
+                lp_absolute.copy_(lp)
+            return
+        _native.logp_rebase(lp, self._shards(), ref, lp_absolute)
+
+    def state_log_prob(self, state):
+        """The relative log-densities a sampler works on, from a sampler state.  States made by `log_prob_state`
+        carry them together with the level they refer to; the level may have moved since (another kernel on the
+        same posterior), which is corrected in double.  A bare state (absolute values only) is converted."""
+        ref = getattr(self.likelihood, 'logp_ref', None)
+        if ref is None:
+            return state['target_log_prob'].clone()
+        level = ref * float(self._shards())
+        if 'relative_log_prob' in state:
+            return (state['relative_log_prob'].double() + (state['log_prob_level'] - level)).float()
+        return (state['target_log_prob'].double() - level).float()
+
+    def log_prob_state(self, lp, lp_absolute=None):
+        """State entries for relative log-densities `lp` under the current level."""
+        ref = getattr(self.likelihood, 'logp_ref', None)
+        if ref is None:
+            return {'target_log_prob': lp}
+        return {'target_log_prob': self.absolute(lp) if lp_absolute is None else lp_absolute,
+                'relative_log_prob': lp, 'log_prob_level': ref * float(self._shards())}
+
+    def absolute(self, lp):
+        """Absolute log-densities for values expressed relative to the current level."""
+        ref = getattr(self.likelihood, 'logp_ref', None)
+        if ref is None:
+            return lp
+        return (lp.double() + ref * float(self._shards())).float()
 
     # ---- constrained space: the closure of mcmc.py:57-62 / vi.py:46-52 ----
     def log_prior(self, theta, want_grad=True):

@@ -27,6 +27,7 @@ class DeviceHamiltonianMonteCarloKernel:
         self.transition = 0
         self.graph_replay = bool(graph_replay)
         self._bufs = None
+        posterior.use_relative_log_prob()
 
     def _buffers(self, z):
         c, pu = z.shape
@@ -34,15 +35,16 @@ class DeviceHamiltonianMonteCarloKernel:
         if self._bufs is None or self._bufs['p'].shape != z.shape:
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=z.device)
             self._bufs = dict(p=f(c, pu), z0=f(c, pu), g0=f(c, pu), lp0=f(c), k0=f(c), theta=f(c, p),
-                              acc=torch.empty(c, dtype=torch.uint8, device=z.device), lr=f(c))
+                              acc=torch.empty(c, dtype=torch.uint8, device=z.device), lr=f(c), lp_abs=f(c))
         return self._bufs
 
     def bootstrap(self, z):
         lp, g = self.posterior.unconstrained_log_prob_and_grad(z, True)
-        return {'target_log_prob': lp.contiguous(), 'grad': g.contiguous()}
+        return dict(self.posterior.log_prob_state(lp.contiguous()), grad=g.contiguous())
 
     def _transition(self, z, g, lp, b, seed, step, momenta=None, log_uniform=None, step_offset=None):
-        """One transition in place on (z, g, lp); accept flags and log ratio land in b['acc'], b['lr']."""
+        """One transition in place on (z, g, lp); accept flags and log ratio land in b['acc'], b['lr'], the
+        absolute log-densities in b['lp_abs'] (lp itself is kept relative to a level that follows the chains)."""
         lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
         c, pu = z.shape
         eps = self.step_size
@@ -65,10 +67,11 @@ class DeviceHamiltonianMonteCarloKernel:
                                       ptr(z), ptr(g), ptr(lp), ptr(b['p']), ptr(b['z0']), ptr(b['g0']),
                                       ptr(b['lp0']), ptr(b['k0']), ptr(b['acc']), ptr(b['lr']), ptr(step_offset), st),
                       'bvi_hmc_end')
+        self.posterior.rebase(lp, b['lp_abs'])
 
     def one_step(self, z, state, generator=None, momenta=None, log_uniform=None):
         z = z.clone().contiguous()          # the kernels update position, gradient and log-prob in place
-        lp = state['target_log_prob'].clone()
+        lp = self.posterior.state_log_prob(state)
         g = state['grad'].clone()
         b = self._buffers(z)
         seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
@@ -76,9 +79,10 @@ class DeviceHamiltonianMonteCarloKernel:
         self.transition += 1
         self._transition(z, g, lp, b, seed, step, momenta, log_uniform)
         acc = b['acc'].to(torch.bool)
-        trace = {'is_accepted': acc, 'target_log_prob': lp, 'log_accept_ratio': b['lr'].clone(),
+        lp_abs = b['lp_abs'].clone()
+        trace = {'is_accepted': acc, 'target_log_prob': lp_abs, 'log_accept_ratio': b['lr'].clone(),
                  'step_size': torch.full((), self.step_size, dtype=z.dtype)}
-        return z, {'target_log_prob': lp, 'grad': g}, trace
+        return z, dict(self.posterior.log_prob_state(lp, lp_abs), grad=g), trace
 
     supports_many_steps = True
     GRAPH_MIN_TRANSITIONS = 8
@@ -96,7 +100,7 @@ class DeviceHamiltonianMonteCarloKernel:
         lik = self.posterior.likelihood
         sharded = getattr(lik, 'sharded', False) or getattr(getattr(lik, 'inner', None), 'sharded', False)
         z = z.clone().contiguous()
-        lp = state['target_log_prob'].clone()
+        lp = self.posterior.state_log_prob(state)
         g = state['grad'].clone()
         c, pu = z.shape
         b = self._buffers(z)
@@ -112,7 +116,7 @@ class DeviceHamiltonianMonteCarloKernel:
         def transition_and_record(step_offset):
             self._transition(z, g, lp, b, seed, base, step_offset=step_offset)
             zs.index_copy_(0, idx, z.unsqueeze(0))
-            lps.index_copy_(0, idx, lp.unsqueeze(0))
+            lps.index_copy_(0, idx, b['lp_abs'].unsqueeze(0))
             lrs.index_copy_(0, idx, b['lr'].unsqueeze(0))
             accs.index_copy_(0, idx, b['acc'].unsqueeze(0))
             idx.add_(1)
@@ -130,7 +134,7 @@ class DeviceHamiltonianMonteCarloKernel:
                 graph.replay()
         traces = {'is_accepted': accs.to(torch.bool), 'target_log_prob': lps, 'log_accept_ratio': lrs,
                   'step_size': torch.full((n,), self.step_size, dtype=z.dtype)}
-        return zs, z, {'target_log_prob': lp, 'grad': g}, traces
+        return zs, z, dict(self.posterior.log_prob_state(lp), grad=g), traces
 
 
 FUSED_MAX_ROWS = 1 << 16     # above this the batched kernels + per-step launches win
@@ -355,6 +359,7 @@ class BatchedDeviceNoUTurnSamplerKernel:
         self.seed = int(seed)
         self.transition = 0
         self._bufs = None
+        posterior.use_relative_log_prob()
 
     def _buffers(self, c, pu, device):
         if self._bufs is None or self._bufs['q'].shape != (c, pu):
@@ -371,12 +376,12 @@ class BatchedDeviceNoUTurnSamplerKernel:
 
     def bootstrap(self, z):
         lp, g = self.posterior.unconstrained_log_prob_and_grad(z, True)
-        return {'target_log_prob': lp.contiguous(), 'grad': g.contiguous()}
+        return dict(self.posterior.log_prob_state(lp.contiguous()), grad=g.contiguous())
 
     def one_step(self, z, state, generator=None):
         lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
         z = z.clone().contiguous()          # the kernels update position, gradient and log-prob in place
-        lp = state['target_log_prob'].clone()
+        lp = self.posterior.state_log_prob(state)
         g = state['grad'].clone()
         c, pu = z.shape
         b = self._buffers(c, pu, z.device)
@@ -419,10 +424,12 @@ class BatchedDeviceNoUTurnSamplerKernel:
         fl = b['flags']
         n_leap = b['n_leap'].to(torch.int64)
         lr = torch.log(torch.clamp(b['sum_acc'] / torch.clamp(n_leap, min=1).to(z.dtype), min=1e-30))
-        trace = {'is_accepted': (fl & _native.NUTS_MOVED) != 0, 'target_log_prob': lp, 'log_accept_ratio': lr,
+        lp_abs = torch.empty_like(lp)
+        self.posterior.rebase(lp, lp_abs)   # lp stays relative to a level that follows the chains
+        trace = {'is_accepted': (fl & _native.NUTS_MOVED) != 0, 'target_log_prob': lp_abs, 'log_accept_ratio': lr,
                  'step_size': torch.full((), self.step_size, dtype=z.dtype), 'leapfrogs_taken': n_leap,
-                 'has_divergence': (fl & _native.NUTS_DIVERGED) != 0, 'energy': -lp}
-        return z, {'target_log_prob': lp, 'grad': g}, trace
+                 'has_divergence': (fl & _native.NUTS_DIVERGED) != 0, 'energy': -lp_abs}
+        return z, dict(self.posterior.log_prob_state(lp, lp_abs), grad=g), trace
 
 
 class DeviceRandomWalkMetropolisKernel:
@@ -446,6 +453,7 @@ class DeviceRandomWalkMetropolisKernel:
         self.seed = int(seed)
         self.transition = 0
         self._bufs = None
+        posterior.use_relative_log_prob()
 
     def _buffers(self, z):
         c, pu = z.shape
@@ -459,7 +467,7 @@ class DeviceRandomWalkMetropolisKernel:
 
     def bootstrap(self, z):
         lp, _ = self.posterior.unconstrained_log_prob_and_grad(z, False)
-        return {'target_log_prob': lp.contiguous()}
+        return self.posterior.log_prob_state(lp.contiguous())
 
     def _transition(self, z, lp, b, seed, step):
         lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
@@ -475,20 +483,21 @@ class DeviceRandomWalkMetropolisKernel:
         _native.check(lib.bvi_hmc_end(c, pu, seed, step, None, ptr(z), ptr(g), ptr(lp), ptr(b['p']), ptr(b['z0']),
                                       ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']), ptr(b['acc']), ptr(b['lr']), None,
                                       st), 'bvi_hmc_end')
+        self.posterior.rebase(lp)           # lp stays relative to a level that follows the chains
 
     def one_step(self, z, state, generator=None):
         z = z.clone().contiguous()
-        lp = state['target_log_prob'].clone()
+        lp = self.posterior.state_log_prob(state)
         b = self._buffers(z)
         seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
         self._transition(z, lp, b, seed, self.transition)
         self.transition += 1
-        return z, {'target_log_prob': lp}, {'is_accepted': b['acc'].to(torch.bool),
-                                             'log_accept_ratio': b['lr'].clone()}
+        return z, self.posterior.log_prob_state(lp), {'is_accepted': b['acc'].to(torch.bool),
+                                                      'log_accept_ratio': b['lr'].clone()}
 
     def many_steps(self, z, state, n, generator=None):
         z = z.clone().contiguous()
-        lp = state['target_log_prob'].clone()
+        lp = self.posterior.state_log_prob(state)
         c, pu = z.shape
         b = self._buffers(z)
         zs = torch.empty(n, c, pu, dtype=torch.float32, device=z.device)
@@ -501,5 +510,5 @@ class DeviceRandomWalkMetropolisKernel:
             accs[t].copy_(b['acc'])
             lrs[t].copy_(b['lr'])
         self.transition += n
-        return zs, z, {'target_log_prob': lp}, {'is_accepted': accs.to(torch.bool), 'log_accept_ratio': lrs}
+        return zs, z, self.posterior.log_prob_state(lp), {'is_accepted': accs.to(torch.bool), 'log_accept_ratio': lrs}
 

@@ -43,6 +43,15 @@ class _MappedLikelihood(ShardedLogLikelihood):
         self.vidx = torch.nonzero(idx >= 0).reshape(-1).to(self.device)
         self.target_cols = idx[idx >= 0].to(self.device)
 
+    @property
+    def logp_ref(self):
+        """The level the wrapped kernels subtract from their log-likelihoods (see FusedLogLikelihood)."""
+        return self.inner.logp_ref
+
+    @logp_ref.setter
+    def logp_ref(self, value):
+        self.inner.logp_ref = value
+
     def logp_grad(self, theta, want_grad=True):
         if self.identity:
             return self.inner.logp_grad(theta, want_grad)

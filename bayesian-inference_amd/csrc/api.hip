@@ -40,19 +40,21 @@ int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, 
 }
 
 int bvi_normal_iid_logp_grad(const float* y, int64_t n, const float* theta, int n_chains, float* logp,
-                             float* grad, void* ws, size_t ws_bytes, void* stream) {
+                             float* grad, const double* logp_ref, void* ws, size_t ws_bytes, void* stream) {
   if ((!y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (!ws || ws_bytes < bvi_ws_normal_iid(n, n_chains)) return BVI_ERR_WORKSPACE;
-  return bvi_launch_normal_iid(y, n, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+  return bvi_launch_normal_iid(y, n, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream, logp_ref);
 }
 
 int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta, int n_chains,
-                         int precision, float* logp, float* grad, void* ws, size_t ws_bytes, void* stream) {
+                         int precision, float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
+                         void* stream) {
   if (((!X || !y) && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X6) return BVI_ERR_ARG;
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_linreg(n, n_chains, d)) return BVI_ERR_WORKSPACE;
-  return bvi_launch_linreg(X, y, n, d, theta, n_chains, precision, logp, grad, (float*)ws, (hipStream_t)stream);
+  return bvi_launch_linreg(X, y, n, d, theta, n_chains, precision, logp, grad, (float*)ws, (hipStream_t)stream,
+                           logp_ref);
 }
 
 int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes) {
@@ -90,36 +92,39 @@ int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, int format
 }
 
 int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, int format, const float* theta,
-                                int n_chains, int precision, float* logp, float* grad, void* ws, size_t ws_bytes,
-                                void* stream) {
+                                int n_chains, int precision, float* logp, float* grad, const double* logp_ref,
+                                void* ws, size_t ws_bytes, void* stream) {
   if ((!packed && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (precision < BVI_PREC_AUTO || precision > BVI_PREC_BF16X6) return BVI_ERR_ARG;
   if (format == BVI_PACK_F16 ? (d < 1 || d > 64) : (d != 32 && d != 64)) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_linreg(n, n_chains, d)) return BVI_ERR_WORKSPACE;
   if (format == BVI_PACK_BF16X3)
     return bvi_launch_linreg_packed(packed, n, d, theta, n_chains, precision, logp, grad, (float*)ws,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, logp_ref);
   if (format == BVI_PACK_F16) {
     if (precision != BVI_PREC_AUTO) return BVI_ERR_UNSUPPORTED;
-    return bvi_launch_linreg_f16(packed, n, d, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+    return bvi_launch_linreg_f16(packed, n, d, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream,
+                                 logp_ref);
   }
   return BVI_ERR_ARG;
 }
 
 int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains, float* logp,
-                        float* grad, void* ws, size_t ws_bytes, void* stream) {
+                        float* grad, const double* logp_ref, void* ws, size_t ws_bytes, void* stream) {
   if ((!y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_gmm1d(n, n_chains, k)) return BVI_ERR_WORKSPACE;
-  return bvi_launch_gmm1d(y, n, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+  return bvi_launch_gmm1d(y, n, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream, logp_ref);
 }
 
 int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
-                              float* logp, float* grad, void* ws, size_t ws_bytes, void* stream) {
+                              float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
+                              void* stream) {
   if ((!Y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
   if (k < 1 || k > 16 || d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
   if (!ws || ws_bytes < bvi_ws_gmm_fullcov(n, n_chains, d, k)) return BVI_ERR_WORKSPACE;
-  return bvi_launch_gmm_fullcov(Y, n, d, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream);
+  return bvi_launch_gmm_fullcov(Y, n, d, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream,
+                                logp_ref);
 }
 
 }  // extern "C"

@@ -32,24 +32,26 @@ static inline int bvi_chain_pack(int c) { return c <= 1 ? 1 : c <= 4 ? 4 : c <= 
 
 // Per-family launchers (defined in the .hip files), all: partial sums into ws,
 // then a finalize kernel that reduces them in fixed order.
+// logp_ref (device pointer or null): a level subtracted from every log-likelihood in double before it is rounded
+// to float, so that callers who only need differences keep them exact when |logp| is large.
 int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, float* logp, float* grad,
-                          float* ws, hipStream_t s);
+                          float* ws, hipStream_t s, const double* logp_ref = nullptr);
 size_t bvi_ws_normal_iid(int64_t n, int c);
 
 int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c, float* logp, float* grad,
-                     float* ws, hipStream_t s);
+                     float* ws, hipStream_t s, const double* logp_ref = nullptr);
 size_t bvi_ws_gmm1d(int64_t n, int c, int k);
 
 int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
-                      float* logp, float* grad, float* ws, hipStream_t s);
+                      float* logp, float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 size_t bvi_ws_linreg(int64_t n, int c, int d);
 size_t bvi_linreg_packed_size(int64_t n, int d);
 int bvi_launch_linreg_pack(const float* X, const float* y, int64_t n, int d, void* packed, hipStream_t s);
 int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* theta, int c, int prec,
-                             float* logp, float* grad, float* ws, hipStream_t s);
+                             float* logp, float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
-                           float* grad, float* ws, hipStream_t s);
+                           float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k);
 
 size_t bvi_linreg_f16_packed_size(int64_t n, int d);
@@ -57,7 +59,7 @@ size_t bvi_linreg_f16_pack_scratch(int d);
 int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,
                                  hipStream_t s);
 int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
-                            float* grad, float* ws, hipStream_t s);
+                            float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 
 #ifdef __HIPCC__
 // Sum of partials p[b * stride], b = 0 .. nb-1, in double and in a fixed order.  WAVE = false: the calling

@@ -89,6 +89,10 @@ __device__ __forceinline__ void mix_row_far(float yj, float keep, const MixParam
 static constexpr float kMixNear = 1.f / (float)(1ull << BVI_GMM_NEAR_LOG2);
 static constexpr float kMixSkip = (float)BVI_GMM_SKIP_LOG2;
 static constexpr int kMixMaxBins = 512;
+// What a lane hands on is sum_i (v_i - kMixRowLevel), v_i = log2 sum_k 2^(Bp_k - u'_ik^2): a row at a typical distance
+// from its component has v ~ -log2(e)/2, so the centred sums stay random-walk sized (floats hold them to ~1e-5 at
+// 100M rows, where the uncentred total is ~1e8); gmm1d_finalize adds n * kMixRowLevel back in double.
+static constexpr float kMixRowLevel = -0.72134752f;
 #ifndef BVI_GMM_UNROLL
 #define BVI_GMM_UNROLL 1
 #endif
@@ -245,8 +249,8 @@ void gmm1d_kernel(const float* __restrict__ y, int64_t n, int kreal,
 #pragma unroll
     for (int q = 1; q < Q; ++q) red[q][threadIdx.x] = 0.f;
   }
-  float tot0 = 0.f;
-  float rows = 0.f;   // rows this lane has added to tot0, each relative to hmax
+  double tot0 = 0.0;  // running total of the per-tile float sums
+  float rows = 0.f;   // rows this lane has added to tot0
 
   const int64_t ntiles = (n + 63) / 64, tstep = (int64_t)gridDim.x * 4;
   int64_t t = (int64_t)blockIdx.x * 4 + wave;
@@ -279,15 +283,13 @@ void gmm1d_kernel(const float* __restrict__ y, int64_t n, int kreal,
         rows += keep;
       }
     }
-    tot0 += acc[0];
+    tot0 += (double)acc[0];
     if (GRAD) {
 #pragma unroll
       for (int q = 1; q < Q; ++q) red[q][threadIdx.x] += acc[q];
     }
   }
-  tot0 = fmaf(rows, p.hmax, tot0);
-
-  red[0][threadIdx.x] = tot0;
+  red[0][threadIdx.x] = (float)(tot0 - (double)rows * (double)kMixRowLevel);
   if (CP < 64) {   // add the row subsets of a wave into its first CP lanes (each thread rewrites its own column)
 #pragma unroll
     for (int q = 0; q < (GRAD ? Q : 1); ++q) red[q][threadIdx.x] = bvi_reduce_over_rowsubs<CP>(red[q][threadIdx.x]);
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict
   if (tid < head) row(y[tid]);
   if (tid < n - tail0) row(y[tail0 + tid]);
 #pragma unroll
-  for (int g = 0; g < CG; ++g) acc[g][0] = fmaf(rows, p[g].hmax, acc[g][0]);
+  for (int g = 0; g < CG; ++g) acc[g][0] = (float)((double)acc[g][0] - (double)rows * (double)kMixRowLevel);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float red[GRAD ? Q : 1][256];
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict
 template <bool WAVE>
 __global__ void gmm1d_finalize(const float* __restrict__ partials, int nb, int64_t n, int k,
                                const float* __restrict__ theta, int C, float* __restrict__ logp,
-                               float* __restrict__ grad) {
+                               float* __restrict__ grad, const double* __restrict__ ref) {
   const int idx = WAVE ? (blockIdx.x * blockDim.x + threadIdx.x) >> 6 : blockIdx.x * blockDim.x + threadIdx.x;
   const int q3 = 3 * k, qreal = 1 + 3 * k;
   if (idx >= C * q3) return;
@@ -374,7 +376,20 @@ __global__ void gmm1d_finalize(const float* __restrict__ partials, int nb, int64
   if (part == 2) ax = bvi_sum_partials<WAVE>(pc + 1 + 2 * k + kk, nb, stride);
   if (j == 0) l2 = bvi_sum_partials<WAVE>(pc, nb, stride);
   if (WAVE && (threadIdx.x & 63) != 0) return;
-  if (j == 0) logp[c] = (float)(l2 * 0.6931471805599453);
+  if (j == 0) {
+    // The kernels sum v_i = log2 sum_k 2^(Bp_k - u'^2) with the FLOAT constants Bp_k and isg_k of mix_load_params.
+    // Those define a parameter vector within float rounding of theta -- scales s~_k = sqrt(log2(e)/2) / isg_k,
+    // weights proportional to 2^Bp_k s~_k -- whose log-density is exactly sum v_i - n (log2 W~ + log2(2 pi)/2),
+    // W~ = sum_k 2^Bp_k s~_k in double: no constant that enters every row is rounded, so the error of the total is
+    // that of the rows' own (unbiased) roundings and not n times a float epsilon.
+    MixParams<16> p;
+    mix_load_params<16>(th, k, p);
+    double wt = 0.0;
+    for (int i = 0; i < k; ++i) wt += exp2((double)p.Bp[i]) * (0.84932180028801904 / (double)p.isg[i]);
+    const double nn = (double)n;
+    l2 += nn * ((double)kMixRowLevel - log2(wt) - 0.5 * 2.6514961294723187);   // log2(2 pi)
+    logp[c] = (float)(l2 * 0.6931471805599453 - (ref ? *ref : 0.0));
+  }
   if (!grad) return;
   const double sc = (double)th[2 * k + kk];
   double g;
@@ -427,7 +442,7 @@ static void gmm1d_dispatch_k(int cp, dim3 grid, hipStream_t s, const float* y, i
 }
 
 int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c, float* logp, float* grad,
-                     float* ws, hipStream_t s) {
+                     float* ws, hipStream_t s, const double* logp_ref) {
   if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
   const int nb = gmm1d_blocks(n);
   const int cp = bvi_chain_pack(c);
@@ -438,10 +453,10 @@ int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c
   const int tot = c * 3 * k;
   if (nb > 32)
     hipLaunchKernelGGL(gmm1d_finalize<true>, dim3(bvi_ceil_div(tot, 4)), dim3(256), 0, s, (const float*)ws, nb, n, k,
-                       theta, c, logp, grad);
+                       theta, c, logp, grad, logp_ref);
   else
     hipLaunchKernelGGL(gmm1d_finalize<false>, dim3(bvi_ceil_div(tot, 128)), dim3(128), 0, s, (const float*)ws, nb, n,
-                       k, theta, c, logp, grad);
+                       k, theta, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

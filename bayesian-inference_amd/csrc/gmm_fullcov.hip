@@ -604,7 +604,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restrict__ partials, int nb, int64_t n,
                                                            int D, int K, const float* __restrict__ theta,
                                                            const float* __restrict__ Ainv, int C,
-                                                           float* __restrict__ logp, float* __restrict__ grad) {
+                                                           float* __restrict__ logp, float* __restrict__ grad,
+                                                           const double* __restrict__ ref) {
   constexpr int Q = 1 + DP + DP * DP, RG = DP / 8;
   const int c = blockIdx.x / K, k = blockIdx.x % K, j = threadIdx.x & (DP - 1), ig = threadIdx.x / DP;
   const int P = K + K * D + K * D * D;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
   if (ig == 0) S1[j] = s1;
   if (threadIdx.x == 0) S0s = s0;
   __syncthreads();
-  if (threadIdx.x == 0 && k == 0) logp[c] = (float)lp;
+  if (threadIdx.x == 0 && k == 0) logp[c] = (float)(lp - (ref ? *ref : 0.0));
   if (!grad) return;
   const float* th = theta + (int64_t)c * P;
   float* gc = grad + (int64_t)c * P;
@@ -679,7 +680,7 @@ size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
 }
 
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
-                           float* grad, float* ws, hipStream_t s) {
+                           float* grad, float* ws, hipStream_t s, const double* logp_ref) {
   if (d < 1 || d > DP || k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
   if (((uintptr_t)ws & 7) != 0) return BVI_ERR_ARG;
   double* psum = (double*)ws;
@@ -735,7 +736,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   }
   BVI_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(8 * DP), 0, s, (const float*)partials, nb, n, d, k, theta,
-                     (const float*)Ainv, c, logp, grad);
+                     (const float*)Ainv, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

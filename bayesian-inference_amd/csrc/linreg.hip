@@ -395,12 +395,13 @@ void linreg_f32_kernel(const float* __restrict__ X,
 // finalize: fixed-order reduction over row blocks (double) + scaling.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void linreg_finish(double s, int c, int q, int64_t n, int d, const float* __restrict__ theta,
-                                              float* __restrict__ logp, float* __restrict__ grad) {
+                                              float* __restrict__ logp, float* __restrict__ grad,
+                                              const double* __restrict__ ref) {
   const int q2 = d + 2;
   const double sc = (double)theta[(int64_t)c * q2 + d + 1];
   const double inv2 = 1.0 / (sc * sc), nn = (double)n;
   if (q == 0) {
-    logp[c] = (float)(-0.5 * s * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
+    logp[c] = (float)(-0.5 * s * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D - (ref ? *ref : 0.0));
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s * inv2 / sc);
   } else if (grad) {
     grad[(int64_t)c * q2 + (q - 1)] = (float)(s * inv2);
@@ -410,20 +411,21 @@ __device__ __forceinline__ void linreg_finish(double s, int c, int q, int64_t n,
 // few row blocks: one thread per (chain, raw-sum index)
 __global__ void linreg_finalize(const float* __restrict__ partials, int nb, int64_t n, int d,
                                 const float* __restrict__ theta, int C, float* __restrict__ logp,
-                                float* __restrict__ grad) {
+                                float* __restrict__ grad, const double* __restrict__ ref) {
   const int q2 = d + 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= C * q2) return;
   const int c = idx / q2, q = idx - c * q2;
   const double s = bvi_sum_partials<false>(partials + (int64_t)c * q2 + q, nb, (int64_t)C * q2);
-  linreg_finish(s, c, q, n, d, theta, logp, grad);
+  linreg_finish(s, c, q, n, d, theta, logp, grad, ref);
 }
 
 // many row blocks: a workgroup owns 64 consecutive outputs (consecutive lanes read consecutive sums of a row
 // block); its 16 waves take every 16th row block and are combined in wave order through LDS
 __global__ __launch_bounds__(1024) void linreg_finalize_tiled(const float* __restrict__ partials, int nb, int64_t n,
                                                               int d, const float* __restrict__ theta, int C,
-                                                              float* __restrict__ logp, float* __restrict__ grad) {
+                                                              float* __restrict__ logp, float* __restrict__ grad,
+                                                              const double* __restrict__ ref) {
   const int q2 = d + 2, tot = C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + o;
@@ -437,17 +439,17 @@ __global__ __launch_bounds__(1024) void linreg_finalize_tiled(const float* __res
   __syncthreads();
   if (grp != 0 || idx >= tot) return;
   for (int w = 1; w < 16; ++w) s += part[w][o];
-  linreg_finish(s, idx / q2, idx % q2, n, d, theta, logp, grad);
+  linreg_finish(s, idx / q2, idx % q2, n, d, theta, logp, grad, ref);
 }
 
 static void launch_linreg_finalize(int tot, hipStream_t s, const float* ws, int nb, int64_t n, int d,
-                                   const float* theta, int c, float* logp, float* grad) {
+                                   const float* theta, int c, float* logp, float* grad, const double* ref) {
   if (nb > 32)
     hipLaunchKernelGGL(linreg_finalize_tiled, dim3(bvi_ceil_div(tot, 64)), dim3(1024), 0, s, ws, nb, n, d, theta, c,
-                       logp, grad);
+                       logp, grad, ref);
   else
     hipLaunchKernelGGL(linreg_finalize, dim3(bvi_ceil_div(tot, 256)), dim3(256), 0, s, ws, nb, n, d, theta, c,
-                       logp, grad);
+                       logp, grad, ref);
 }
 
 // ---------------------------------------------------------------------------
@@ -512,7 +514,7 @@ static void linreg_f32_dispatch(int nc, dim3 grid, hipStream_t s, const float* X
 }
 
 int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* theta, int c, int prec,
-                             float* logp, float* grad, float* ws, hipStream_t s) {
+                             float* logp, float* grad, float* ws, hipStream_t s, const double* logp_ref) {
   if (d != 32 && d != 64) return BVI_ERR_UNSUPPORTED;
   if (prec == BVI_PREC_F32) return BVI_ERR_UNSUPPORTED;
   int nb;
@@ -520,13 +522,13 @@ int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* 
                                           ws, &nb, s);
   if (st != BVI_OK) return st;
   const int tot = c * (d + 2);
-  launch_linreg_finalize(tot, s, ws, nb, n, d, theta, c, logp, grad);
+  launch_linreg_finalize(tot, s, ws, nb, n, d, theta, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
 
 int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const float* theta, int c, int prec,
-                      float* logp, float* grad, float* ws, hipStream_t s) {
+                      float* logp, float* grad, float* ws, hipStream_t s, const double* logp_ref) {
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
   if ((prec == BVI_PREC_BF16X3 || prec == BVI_PREC_BF16X6) && !use_bf16x3(n, d, c, prec)) return BVI_ERR_UNSUPPORTED;
   int nb;
@@ -564,7 +566,7 @@ int bvi_launch_linreg(const float* X, const float* y, int64_t n, int d, const fl
     BVI_HIP_CHECK_LAUNCH();
   }
   const int tot = c * (d + 2);
-  launch_linreg_finalize(tot, s, ws, nb, n, d, theta, c, logp, grad);
+  launch_linreg_finalize(tot, s, ws, nb, n, d, theta, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

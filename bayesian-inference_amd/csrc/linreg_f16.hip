@@ -227,9 +227,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int i = 0; i < 4; ++i) G[ct][ft][i] = 0.f;
-  float s2[CT];
+  // per-tile sums of squares are floats, their running total a double: at 10M rows a chain's S2' is ~1e7 times a
+  // typical square, and the log-density differences a sampler decides on must come out to ~1e-3 of one square
+  double s2[CT];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) s2[ct] = 0.f;
+  for (int ct = 0; ct < CT; ++ct) s2[ct] = 0.0;
 
   // chunk q of row r lives at chunk q ^ swz(r): with it the A-operand ds_read_b128 (lane groups
   // {0-3,12-15,20-27}, ...: 16 rows, two neighbouring chunks), the transposed ds_read_b64_tr_b16 (32 lanes:
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     }
     }
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) s2[ct] += a2[ct];
+    for (int ct = 0; ct < CT; ++ct) s2[ct] += (double)a2[ct];
     lstore(buf ^ 1);     // as late as possible: the whole tile's arithmetic covers the HBM latency of gload
     __syncthreads();
     buf ^= 1;
@@ -370,14 +372,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
 
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    float v = s2[ct];
+    double v = s2[ct];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     const int chain = cbase + 16 * ct + ln;
     if (chain < C && g == 0) {
+      // S2' as a float pair (high part, remainder); S1 comes from the packed data sums (finalize)
       float* p = partials + ((int64_t)rbi * C + chain) * (dr + 2);
-      p[0] = v;
-      p[1] = 0.f;   // S1 comes from the packed data sums (finalize)
+      p[0] = (float)v;
+      p[1] = (float)(v - (double)(float)v);
     }
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
@@ -486,7 +489,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int i = 0; i < 4; ++i) G[ct][ft][i] = 0.f;
-  float s2[CT] = {0.f, 0.f}, a2[CT] = {0.f, 0.f};
+  double s2[CT] = {0.0, 0.0};   // running total of the per-block float sums a2 (see linreg_f16_kernel)
+  float a2[CT] = {0.f, 0.f};
 
   // tiles of this row block: rbi, rbi + nrb, ...
   const int64_t nt = rbi < ntiles ? (ntiles - rbi + nrb - 1) / nrb : 0;
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         });
       });
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) { s2[ct] += a2[ct]; a2[ct] = 0.f; }
+      for (int ct = 0; ct < CT; ++ct) { s2[ct] += (double)a2[ct]; a2[ct] = 0.f; }
       lstore(rnxt == RING - 1 ? 0 : rnxt + 1);
       __syncthreads();
       rcur = rnxt;
@@ -682,14 +686,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    float v = s2[ct];
+    double v = s2[ct];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     const int chain = cbase + 16 * ct + ln;
     if (chain < C && g == 0) {
       float* p = partials + ((int64_t)rbi * C + chain) * (dr + 2);
-      p[0] = v;
-      p[1] = 0.f;
+      p[0] = (float)v;
+      p[1] = (float)(v - (double)(float)v);
     }
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
@@ -972,7 +976,7 @@ template <int kFinGroups>
 __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     const float* __restrict__ partials, int nb, int64_t n, int d, int dplane, int cpb,
     const unsigned char* __restrict__ packed, const float* __restrict__ theta, int C, float* __restrict__ logp,
-    float* __restrict__ grad) {
+    float* __restrict__ grad, const double* __restrict__ ref) {
   const int c = blockIdx.x, q2 = d + 2;
   const int64_t tot = (int64_t)C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1003,7 +1007,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   for (int q0 = 0; q0 < q2; q0 += 64) {
     const int q = q0 + o;
     double s = 0.0;
-    if (q < q2 && q != 1) {
+    if (q < q2) {
 #pragma unroll 16
       for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + (int64_t)c * q2 + q];
     }
@@ -1070,10 +1074,10 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     // padding rows of the last tile came through as r' = fma(ypad, t, -t (b0 - ybar)): out again
     const double npad = (double)((n + kTileRows - 1) / kTileRows * kTileRows - n);
     const float rpad = fmaf(pad_target(theta, (c / cpb) * cpb, d, hdr->ybar), sh_t, -b0c * sh_t);
-    double s2 = (sums[0] - npad * (double)rpad * (double)rpad) / (u * u);
+    double s2 = (sums[0] + sums[1] - npad * (double)rpad * (double)rpad) / (u * u);   // S2' arrives as a float pair
     s2 += -2.0 * db * (hdr->ysum - nn * b0_eff) + nn * db * db;
     for (int f = 0; f < d; ++f) s2 += s2t[f];
-    logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
+    logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D - (ref ? *ref : 0.0));
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
   } else if (threadIdx.x == 64 && grad) {
     double s1 = hdr->ysum - nn * (double)th[0];
@@ -1143,7 +1147,7 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
 
 template <int D, int NW, int CT>
 static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* theta, int c, float* logp, float* grad,
-                      float* ws, hipStream_t s) {
+                      float* ws, hipStream_t s, const double* logp_ref) {
   constexpr int cpb = 16 * CT * NW;
   // NW = 8: one workgroup per CU; NW = 4 (at most 128 chains): two per CU, each on its own row blocks
   // (one tile per wave: three per CU on a large dataset -- the kernel is then bound by its own HBM stream, and
@@ -1178,16 +1182,16 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   BVI_HIP_CHECK_LAUNCH();
   if (c > 256)
     hipLaunchKernelGGL(linreg_f16_finalize<4>, dim3(c), dim3(256), 0, s, (const float*)ws, nrb, n, d, D, cpb, pk, theta,
-                       c, logp, grad);
+                       c, logp, grad, logp_ref);
   else
     hipLaunchKernelGGL(linreg_f16_finalize<16>, dim3(c), dim3(1024), 0, s, (const float*)ws, nrb, n, d, D, cpb, pk, theta,
-                       c, logp, grad);
+                       c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
 
 int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* theta, int c, float* logp,
-                          float* grad, float* ws, hipStream_t s) {
+                          float* grad, float* ws, hipStream_t s, const double* logp_ref) {
   if (((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
   if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
   const unsigned char* pk = (const unsigned char*)packed;
@@ -1197,11 +1201,11 @@ int bvi_launch_linreg_f16(const void* packed, int64_t n, int d, const float* the
   // to the memory system's pace (N = 10M, D = 64, 64 chains: 0.73 ms against 1.05 ms).
   const bool wide = plane_cols(d) == 64;
   if (c <= 64)
-    return wide ? launch_f16<64, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s)
-                : launch_f16<32, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s);
+    return wide ? launch_f16<64, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s, logp_ref)
+                : launch_f16<32, 4, 1>(pk, n, d, theta, c, logp, grad, ws, s, logp_ref);
   if (c <= 128)
-    return wide ? launch_f16<64, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s)
-                : launch_f16<32, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s);
-  return wide ? launch_f16<64, 8, 2>(pk, n, d, theta, c, logp, grad, ws, s)
-              : launch_f16<32, 8, 2>(pk, n, d, theta, c, logp, grad, ws, s);
+    return wide ? launch_f16<64, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s, logp_ref)
+                : launch_f16<32, 4, 2>(pk, n, d, theta, c, logp, grad, ws, s, logp_ref);
+  return wide ? launch_f16<64, 8, 2>(pk, n, d, theta, c, logp, grad, ws, s, logp_ref)
+              : launch_f16<32, 8, 2>(pk, n, d, theta, c, logp, grad, ws, s, logp_ref);
 }

@@ -18,6 +18,15 @@
 #include "bvi_common.h"
 #include <mutex>
 
+// The rows are summed around loc with its 12 lowest mantissa bits cleared: y - loc_hi is then exact for every y
+// within 2^12 of loc's size, whereas fl(y - loc) with all 24 bits of loc in play rounds a fixed fraction of the rows
+// the same way for some bit patterns of loc (measured at 100M rows: a shift of the log-density by +-0.1 that comes
+// and goes with loc's last bits).  normal_iid_finalize moves the sums to loc itself in double:
+//   S1 = S1' - n lo,   S2 = S2' - 2 lo S1' + n lo^2,   lo = loc - loc_hi.
+__device__ __forceinline__ float normal_loc_hi(float loc) {
+  return __uint_as_float(__float_as_uint(loc) & 0xFFFFF000u);
+}
+
 template <int CP>
 __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict__ y, int64_t n,
                                                          const float* __restrict__ theta, int C,
@@ -27,8 +36,14 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform by construction
   const int cl = lane & (CP - 1), rsub = lane / CP;
   const int chain = blockIdx.y * CP + cl;
-  const float mu = chain < C ? theta[2 * chain] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
+  const float mu = chain < C ? normal_loc_hi(theta[2 * chain]) : 0.f;
+  // S2 ~ n scale^2 is 1e8 times a typical square at 100M rows, and the log-density differences a sampler decides on
+  // must come out to a fraction of one square: per-tile sums are floats, their running total is a double, and what
+  // leaves the lane is S2 - rows * scale^2 (small near the posterior); finalize adds n * scale^2 back in double
+  const double sig2 = chain < C ? (double)theta[2 * chain + 1] * (double)theta[2 * chain + 1] : 0.0;
+  float s1 = 0.f;
+  double s2 = 0.0;
+  int rows = 0;
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
     float a1 = 0.f, a2 = 0.f;
@@ -45,7 +60,8 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
         a2 = fmaf(r0, r0, a2); b2 = fmaf(r1, r1, b2); c2 = fmaf(r2, r2, c2); d2 = fmaf(r3, r3, d2);
       }
       s1 += (a1 + b1) + (c1 + d1);
-      s2 += (a2 + b2) + (c2 + d2);
+      s2 += (double)((a2 + b2) + (c2 + d2));
+      rows += 64;
       continue;
     }
     const int64_t i = t * 64 + lane;
@@ -57,25 +73,28 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
         a1 += r;
         a2 = fmaf(r, r, a2);
       }
+      rows += CP;
     } else {
 #pragma unroll
       for (int j = 0; j < CP; ++j) {
         const int src = rsub + RS * j;
         float r = __shfl(yv, src, 64) - mu;
-        r = (t * 64 + src < n) ? r : 0.f;
+        const bool valid = t * 64 + src < n;
+        r = valid ? r : 0.f;
+        rows += valid ? 1 : 0;
         a1 += r;
         a2 = fmaf(r, r, a2);
       }
     }
     s1 += a1;
-    s2 += a2;
+    s2 += (double)a2;
   }
   s1 = bvi_reduce_over_rowsubs<CP>(s1);
-  s2 = bvi_reduce_over_rowsubs<CP>(s2);
+  const float s2c = bvi_reduce_over_rowsubs<CP>((float)(s2 - (double)rows * sig2));
   __shared__ float sm[4][CP][2];
   if (rsub == 0) {
     sm[wave][cl][0] = s1;
-    sm[wave][cl][1] = s2;
+    sm[wave][cl][1] = s2c;
   }
   __syncthreads();
   if (threadIdx.x < CP) {
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(256) void normal_iid_rows_kernel(const float* __res
   float mu[CG], s1[CG], s2[CG];
 #pragma unroll
   for (int k = 0; k < CG; ++k) {
-    mu[k] = c0 + k < C ? theta[2 * (c0 + k)] : 0.f;
+    mu[k] = c0 + k < C ? normal_loc_hi(theta[2 * (c0 + k)]) : 0.f;
     s1[k] = 0.f;
     s2[k] = 0.f;
   }
@@ -141,12 +160,18 @@ __global__ __launch_bounds__(256) void normal_iid_rows_kernel(const float* __res
   }
   if (tid < head) row(y[tid]);
   if (tid < n - tail0) row(y[tail0 + tid]);
+  // rows this lane has summed (a few hundred at most: its float sums are accurate); what leaves the lane is
+  // S2 - rows * scale^2, small near the posterior, and finalize adds n * scale^2 back in double
+  const double rows = (double)(4 * (tid < n4 ? (n4 - tid + nth - 1) / nth : 0) + (tid < head ? 1 : 0) +
+                               (tid < n - tail0 ? 1 : 0));
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float sm[4][CG][2];
 #pragma unroll
   for (int k = 0; k < CG; ++k) {
-    const float t1 = bvi_reduce_over_rowsubs<1>(s1[k]), t2 = bvi_reduce_over_rowsubs<1>(s2[k]);
+    const double sc = c0 + k < C ? (double)theta[2 * (c0 + k) + 1] : 0.0;
+    const float t1 = bvi_reduce_over_rowsubs<1>(s1[k]);
+    const float t2 = bvi_reduce_over_rowsubs<1>((float)((double)s2[k] - rows * sc * sc));
     if (lane == 0) {
       sm[wave][k][0] = t1;
       sm[wave][k][1] = t2;
@@ -165,15 +190,19 @@ __global__ __launch_bounds__(256) void normal_iid_rows_kernel(const float* __res
 template <bool WAVE>
 __global__ void normal_iid_finalize(const float* __restrict__ partials, int nb, int64_t n,
                                     const float* __restrict__ theta, int C, float* __restrict__ logp,
-                                    float* __restrict__ grad) {
+                                    float* __restrict__ grad, const double* __restrict__ ref) {
   const int c = WAVE ? (blockIdx.x * blockDim.x + threadIdx.x) >> 6 : blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double s1 = bvi_sum_partials<WAVE>(partials + (int64_t)c * 2, nb, (int64_t)C * 2);
-  const double s2 = bvi_sum_partials<WAVE>(partials + (int64_t)c * 2 + 1, nb, (int64_t)C * 2);
+  const double s1h = bvi_sum_partials<WAVE>(partials + (int64_t)c * 2, nb, (int64_t)C * 2);
+  const double s2c = bvi_sum_partials<WAVE>(partials + (int64_t)c * 2 + 1, nb, (int64_t)C * 2);
   if (WAVE && (threadIdx.x & 63) != 0) return;
   const double sc = (double)theta[2 * c + 1], nn = (double)n;
   const double inv2 = 1.0 / (sc * sc);
-  logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D);
+  // the kernels hand over S1', S2' - rows * scale^2 taken around loc_hi
+  const double lo = (double)theta[2 * c] - (double)normal_loc_hi(theta[2 * c]);
+  const double s1 = s1h - nn * lo;
+  const double s2 = s2c + nn * sc * sc - 2.0 * lo * s1h + nn * lo * lo;
+  logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D - (ref ? *ref : 0.0));
   if (grad) {
     grad[2 * c] = (float)(s1 * inv2);
     grad[2 * c + 1] = (float)(-nn / sc + s2 * inv2 / sc);
@@ -188,7 +217,7 @@ static int normal_iid_blocks(int64_t n) {
 size_t bvi_ws_normal_iid(int64_t n, int c) { return (size_t)normal_iid_blocks(n) * c * 2 * sizeof(float); }
 
 int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, float* logp, float* grad,
-                          float* ws, hipStream_t s) {
+                          float* ws, hipStream_t s, const double* logp_ref) {
   const int nb = normal_iid_blocks(n);
   const int cp = bvi_chain_pack(c);
   dim3 grid(nb, bvi_ceil_div(c, cp));
@@ -201,10 +230,10 @@ int bvi_launch_normal_iid(const float* y, int64_t n, const float* theta, int c, 
   BVI_HIP_CHECK_LAUNCH();
   if (nb > 32)
     hipLaunchKernelGGL(normal_iid_finalize<true>, dim3(bvi_ceil_div(c, 4)), dim3(256), 0, s, (const float*)ws, nb, n,
-                       theta, c, logp, grad);
+                       theta, c, logp, grad, logp_ref);
   else
     hipLaunchKernelGGL(normal_iid_finalize<false>, dim3(bvi_ceil_div(c, 128)), dim3(128), 0, s, (const float*)ws, nb,
-                       n, theta, c, logp, grad);
+                       n, theta, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void nuts_leaf_kernel(bvi_nuts_state s, uint6
   for (int j = lane; j < Pu; j += nt) ke = fmaf(0.5f * s.p[o + j], s.p[o + j], ke);
   ke = block_reduce<false>(ke, red);
   const float lpq = s.lpq[c];
-  float dh = (-lpq + ke) - s.h0[c];
+  float dh = (float)(((double)ke - (double)lpq) - (double)s.h0[c]);   // small differences of stored levels: in double
   if (!isfinite(dh)) dh = INFINITY;
   const bool div_now = dh > s.max_energy_diff;
   const bool ok = !div_now;

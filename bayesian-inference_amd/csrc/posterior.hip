@@ -330,7 +330,9 @@ __global__ __launch_bounds__(1024) void hmc_end_kernel(int C, int Pu, uint64_t s
     k1 += 0.5f * pj * pj;
   }
   k1 = block_reduce<false>(k1, red);
-  float lr = (lp[c] - k1) - (lp0[c] - k0[c]);
+  // the energy difference in double: log-densities are stored relative to a level that keeps them small
+  // (bvi_logp_rebase), so the two differences below are exact and so is their sum to float rounding
+  float lr = (float)(((double)lp[c] - (double)lp0[c]) - ((double)k1 - (double)k0[c]));
   if (!isfinite(lr)) lr = -INFINITY;
   const float lu = log_u_in ? log_u_in[c] : logf(u01(draw(seed, step, c, 0, 1).x));
   const bool acc = lu < lr;
@@ -346,6 +348,34 @@ __global__ __launch_bounds__(1024) void hmc_end_kernel(int C, int Pu, uint64_t s
     accepted[c] = acc ? 1 : 0;
     log_ratio_out[c] = lr;
   }
+}
+
+// Re-levels the stored log-densities of all chains: m = the largest finite lp[c]; lp[c] -= m; *ref += m / shards.
+// With ref handed to the likelihood entry points as logp_ref, every later evaluation comes out relative to the new
+// level, i.e. small wherever the chains are, and differences between a proposal and the current state keep float
+// precision however large the log-density itself is (at 10M rows |log pi| ~ 1e7, where floats are 1 apart).
+// lp_abs (optional) receives the absolute values, float(lp[c] + shards * ref), as they were before this call.
+__global__ __launch_bounds__(1024) void logp_rebase_kernel(int C, float* __restrict__ lp, int shards,
+                                                           double* __restrict__ ref, float* __restrict__ lp_abs) {
+  __shared__ float red[16];
+  const double level = *ref * (double)shards;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float v = lp[c];
+    if (isfinite(v)) m = fmaxf(m, v);
+  }
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();                       // also: every thread has read *ref before thread 0 rewrites it
+  m = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+  if (!isfinite(m)) m = 0.f;             // no chain with a finite density: nothing to level
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float v = lp[c];
+    if (lp_abs) lp_abs[c] = (float)((double)v + level);
+    lp[c] = v - m;
+  }
+  if (threadIdx.x == 0) *ref += (double)m / (double)shards;
 }
 
 inline dim3 chain_grid(int C) { return dim3(bvi_ceil_div(C, 64)); }
@@ -487,6 +517,14 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
                      n_chains,
                      n_unconstrained, seed, step, log_u_in, z, grad_z, lp, p, z0, g0, lp0, k0, is_accepted,
                      log_accept_ratio, step_offset);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
+int bvi_logp_rebase(int n_chains, float* lp, int n_shards, double* logp_ref, float* lp_absolute, void* stream) {
+  if (!lp || !logp_ref || n_chains < 1 || n_shards < 1) return BVI_ERR_ARG;
+  hipLaunchKernelGGL(logp_rebase_kernel, dim3(1), dim3(n_chains > 256 ? 1024 : 256), 0, (hipStream_t)stream, n_chains,
+                     lp, n_shards, logp_ref, lp_absolute);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

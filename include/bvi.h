@@ -29,6 +29,12 @@
  *     bayes_vi/inference/mcmc/mcmc.py:83-99, bayes_vi/model/model.py:123-153);
  *   - `grad` may be NULL: value only (RandomWalkMetropolis,
  *     bayes_vi/inference/mcmc/transition_kernels.py:319-321);
+ *   - `logp_ref` (device pointer to one double, or NULL for 0): a level that is subtracted from every
+ *     logp[c] in double before it is rounded to float.  A float holds a log-likelihood of 1e7 (10M rows)
+ *     to +-0.5, which is the size of the differences a Metropolis test decides on; callers that only use
+ *     differences (every sampler) keep a level near the chains' current values there -- bvi_logp_rebase
+ *     maintains one -- and the outputs stay small and exact.  The reference has no such argument: TFP
+ *     carries float32 log-probs and takes the rounding.  Row shards each subtract their own level.
  *   - non-finite parameters give non-finite outputs, never an error: the
  *     sampler turns them into rejections as the reference does.
  */
@@ -42,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 102
+#define BVI_VERSION 103
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -112,7 +118,8 @@ int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, 
  * bayes_vi/model/model.py:17-21,197-203 for README.md:119-120, and its gradient
  * taken by tfp.mcmc kernels (transition_kernels.py:122-128, 238-246). */
 int bvi_normal_iid_logp_grad(const float* y, int64_t n, const float* theta, int n_chains,
-                             float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+                             float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
+                             void* stream);
 
 /* The same computation as bvi_normal_iid_logp_grad WITHOUT a workspace argument and without any allocation:
  * the per-row-block partial sums live in a device array inside the library (2 MiB, held on every GPU the library
@@ -135,7 +142,7 @@ int bvi_normal_iid_logp_grad_noalloc(const float* y, int64_t n, const float* the
  * bvi_linreg_pack(BVI_PACK_F16) and call bvi_linreg_packed_logp_grad: at n = 10M, d = 64, 1024 chains that is
  * 3.5 ms per evaluation against 8.2 ms here, and half the HBM traffic at few chains. */
 int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta,
-                         int n_chains, int precision, float* logp, float* grad,
+                         int n_chains, int precision, float* logp, float* grad, const double* logp_ref,
                          void* ws, size_t ws_bytes, void* stream);
 
 /* The same likelihood on a dataset packed once for the matrix-core kernels.
@@ -164,15 +171,15 @@ int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes);
 int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, int format, void* packed,
                     size_t packed_bytes, void* ws, size_t ws_bytes, void* stream);
 int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, int format, const float* theta,
-                                int n_chains, int precision, float* logp, float* grad, void* ws,
-                                size_t ws_bytes, void* stream);
+                                int n_chains, int precision, float* logp, float* grad, const double* logp_ref,
+                                void* ws, size_t ws_bytes, void* stream);
 
 /* Univariate Gaussian mixture: y[n], theta[C,3k] = (weights_k, loc_k, scale_k)
  * -> logp[C], grad[C,3k].  Weights are normalised by their sum, as
  * Categorical(probs=weights) does.  Replaces the likelihood node for
  * exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15. */
 int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains,
-                        float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+                        float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes, void* stream);
 
 /* Full-covariance Gaussian mixture: Y[n,d] row-major,
  * theta[C, k + k*d + k*d*d] = (weights_k, locs[k][d], scale_tril[k][d][d] row-major, entries above the
@@ -183,7 +190,8 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
  * MixtureSameFamily(Categorical(probs), MultivariateNormalTriL(locs, scale_tril)) of
  * exploratory_experiments/multivariate-gaussian-mixture-density-estimation-test.ipynb cell 7. */
 int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
-                              float* logp, float* grad, void* ws, size_t ws_bytes, void* stream);
+                              float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* ---- device-side posterior assembly: what tfp.mcmc.TransformedTransitionKernel adds around the
  * target closure (bayes_vi/inference/mcmc/mcmc.py:153-156).  `blocks` is a HOST array.  With
@@ -228,6 +236,14 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
                 float* z, float* grad_z, float* lp, const float* p, const float* z0, const float* g0,
                 const float* lp0, const float* k0, unsigned char* is_accepted, float* log_accept_ratio,
                 const uint64_t* step_offset, void* stream);
+
+/* Keeps the stored log-densities of all chains small: m = the largest finite lp[c]; lp[c] -= m;
+ * *logp_ref += m / n_shards (each of the n_shards row shards subtracts its own *logp_ref inside the likelihood
+ * entry points, so the total level moves by m).  lp_absolute (may be NULL) receives float(lp[c] + n_shards *
+ * *logp_ref) as it was before the call: the value the reference would report as target_log_prob.  Called between
+ * transitions (after bvi_hmc_end / bvi_nuts_subtree_end), when lp holds the chains' current states only.  No
+ * counterpart in the reference (TFP keeps float32 log-probs); allocates nothing, capturable in a HIP graph. */
+int bvi_logp_rebase(int n_chains, float* lp, int n_shards, double* logp_ref, float* lp_absolute, void* stream);
 
 /* The two leapfrog halves with one signed step size per chain (step_sizes[C]; 0 leaves a chain untouched):
  * what the No-U-Turn sampler needs, whose chains integrate forwards or backwards in time and stop at

@@ -22,11 +22,11 @@ def test_noalloc_entry_point_matches_workspace_entry_point(gpu_device):
         ref_lp, ref_g = nat.normal_iid_logp_grad(y, th, ws)
         lp = torch.full((c,), float('nan'), device=gpu_device)
         gr = torch.full((c, 2), float('nan'), device=gpu_device)
-        before = torch.cuda.memory_allocated()
+        before = torch.cuda.memory_stats()['allocation.all.allocated']      # a counter: frees elsewhere do not move it
         st = lib.bvi_normal_iid_logp_grad_noalloc(nat._ptr(y), n, nat._ptr(th), c, nat._ptr(lp), nat._ptr(gr),
                                                   nat._stream())
         assert st == 0, lib.bvi_status_string(st)
-        assert torch.cuda.memory_allocated() == before
+        assert torch.cuda.memory_stats()['allocation.all.allocated'] == before
         torch.cuda.synchronize()
         assert torch.equal(lp, ref_lp) and torch.equal(gr, ref_g)
         # value only
