@@ -321,6 +321,16 @@ class Posterior:
             return
         _native.logp_rebase(lp, self._shards(), ref, lp_absolute)
 
+    def initial_log_prob_and_grad(self, z, want_grad=True):
+        """First evaluation of a run: with a level in use, one pass finds it (the values of that pass are absolute
+        floats, +-0.5 at |log pi| ~ 1e7), the level moves to the best chain, and a second pass returns values
+        relative to it -- so that a chain which rejects its first proposals does not keep a rounded log-density."""
+        lp, g = self.unconstrained_log_prob_and_grad(z, want_grad)
+        if getattr(self.likelihood, 'logp_ref', None) is not None:
+            self.rebase(lp.contiguous())
+            lp, g = self.unconstrained_log_prob_and_grad(z, want_grad)
+        return lp, g
+
     def state_log_prob(self, state):
         """The relative log-densities a sampler works on, from a sampler state.  States made by `log_prob_state`
         carry them together with the level they refer to; the level may have moved since (another kernel on the

@@ -39,7 +39,7 @@ class DeviceHamiltonianMonteCarloKernel:
         return self._bufs
 
     def bootstrap(self, z):
-        lp, g = self.posterior.unconstrained_log_prob_and_grad(z, True)
+        lp, g = self.posterior.initial_log_prob_and_grad(z, True)
         return dict(self.posterior.log_prob_state(lp.contiguous()), grad=g.contiguous())
 
     def _transition(self, z, g, lp, b, seed, step, momenta=None, log_uniform=None, step_offset=None):
@@ -375,7 +375,7 @@ class BatchedDeviceNoUTurnSamplerKernel:
         return self._bufs
 
     def bootstrap(self, z):
-        lp, g = self.posterior.unconstrained_log_prob_and_grad(z, True)
+        lp, g = self.posterior.initial_log_prob_and_grad(z, True)
         return dict(self.posterior.log_prob_state(lp.contiguous()), grad=g.contiguous())
 
     def one_step(self, z, state, generator=None):
@@ -466,7 +466,7 @@ class DeviceRandomWalkMetropolisKernel:
         return self._bufs
 
     def bootstrap(self, z):
-        lp, _ = self.posterior.unconstrained_log_prob_and_grad(z, False)
+        lp, _ = self.posterior.initial_log_prob_and_grad(z, False)
         return self.posterior.log_prob_state(lp.contiguous())
 
     def _transition(self, z, lp, b, seed, step):

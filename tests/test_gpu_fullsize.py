@@ -109,6 +109,107 @@ def test_regression_10m_rows_few_chains_through_the_host_mirror(nat, ws, regress
     assert torch.equal(lp, lp_v)
 
 
+def _level_of(nat, lp):
+    """The level bvi_logp_rebase picks for these log-densities (their largest finite value), as a device double."""
+    ref = torch.zeros(1, dtype=torch.float64, device=lp.device)
+    nat.logp_rebase(lp.clone(), 1, ref)
+    return ref
+
+
+def test_log_density_differences_at_10m_rows(nat, ws, regression_10m):
+    """What a Metropolis / NUTS energy test consumes is the DIFFERENCE of two log-densities.  At 10M rows
+    |log-likelihood| ~ 1.4e7, where floats are 1 apart, so absolute float outputs carry +-0.5 of noise per decision;
+    relative to a level near the chains (logp_ref) the same kernels return differences good to 1e-2.  64 chains
+    within the posterior's own width of the mode, against float64 sufficient statistics; the device sampler's
+    state through the same check."""
+    r = regression_10m
+    n, d, dev = r['n'], r['d'], r['X'].device
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    beta = torch.linalg.solve(r['A'], r['b'])
+    sig = torch.sqrt((r['yy'] - beta @ r['b']) / n)
+    c = 64
+    th = torch.cat([beta[None] + 3e-4 * torch.randn(c, d + 1, generator=g, device=dev, dtype=torch.float64),
+                    sig * (1 + 2e-4 * torch.randn(c, 1, generator=g, device=dev, dtype=torch.float64))], -1).float().contiguous()
+    ref64, _, _ = _reference_from_stats(r, th)
+    assert float(ref64.max() - ref64.min()) < 1e3                 # nearby: the differences are O(parameters)
+    pk = nat.linreg_pack(r['X'], r['y'], fmt=nat.PACK_F16)
+    lp_abs, _ = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
+    err_abs = lp_abs.double() - ref64
+    level = _level_of(nat, lp_abs)
+    for cc in (64, 16):                                            # two-tile-per-wave and one-tile-per-wave kernels
+        lp, _ = nat.linreg_packed_logp_grad(pk, n, d, th[:cc].contiguous(), ws, fmt=nat.PACK_F16, logp_ref=level)
+        err = lp.double() + level - ref64[:cc]
+        assert float((err - err.mean()).abs().max()) <= 1e-2, float((err - err.mean()).abs().max())
+        lpv, _ = nat.linreg_packed_logp_grad(pk, n, d, th[:cc].contiguous(), ws, want_grad=False, fmt=nat.PACK_F16,
+                                             logp_ref=level)
+        assert torch.equal(lp, lpv)
+    # the absolute float outputs cannot do that (documented, not required): their spread is the float spacing
+    assert float((err_abs - err_abs.mean()).abs().max()) > 0.1
+    # two row shards, each relative to its own level (half of the total, as bvi_logp_rebase leaves them): they add
+    cut = 4_999_937
+    half = level / 2
+    parts = []
+    for lo, hi in ((0, cut), (cut, n)):
+        Xs, ys = r['X'][lo:hi], r['y'][lo:hi]
+        if Xs.data_ptr() % 16:
+            Xs = Xs.clone()
+        if ys.data_ptr() % 16:
+            ys = ys.clone()
+        pks = nat.linreg_pack(Xs, ys, fmt=nat.PACK_F16)
+        parts.append(nat.linreg_packed_logp_grad(pks, hi - lo, d, th, ws, fmt=nat.PACK_F16, logp_ref=half)[0])
+        del pks
+    err = (parts[0] + parts[1]).double() + level - ref64
+    assert float((err - err.mean()).abs().max()) <= 1.5e-2
+    del pk
+
+
+def test_device_hmc_keeps_relative_log_densities_at_10m_rows(regression_10m, gpu_device):
+    """Device HMC on the 10M-row regression: the state's log-densities are stored relative to a level that
+    bvi_logp_rebase moves with the chains (largest current value = 0), the reported target_log_prob is absolute, and
+    both agree with float64 -- the relative ones to 1e-2 (plus the priors' float rounding), which absolute floats
+    (1 apart at 1.4e7) cannot."""
+    from bayes_vi_amd import bijectors as tfb, distributions as tfd
+    from bayes_vi_amd.fused_target import LinearRegression, Posterior
+    from bayes_vi_amd.inference.mcmc.device_hmc import DeviceHamiltonianMonteCarloKernel
+    r = regression_10m
+    n, d = r['n'], r['d']
+    lik = r.get('lik') or LinearRegression(r['X'], r['y'])
+    r['lik'] = lik
+    lik.logp_ref = None
+    post = Posterior(lik, [(tfd.Normal(0., 10.), 1), (tfd.Normal(torch.zeros(d), 10.), d), (tfd.HalfNormal(10.), 1)],
+                     [tfb.Identity(), tfb.Identity(), tfb.Softplus()])
+    g = torch.Generator(device=gpu_device); g.manual_seed(3)
+    beta = torch.linalg.solve(r['A'], r['b'])
+    sig = torch.sqrt((r['yy'] - beta @ r['b']) / n)
+    c = 32
+    z = torch.cat([beta[None] + 2e-4 * torch.randn(c, d + 1, generator=g, device=gpu_device, dtype=torch.float64),
+                   torch.log(torch.expm1(sig)) + 1e-4 * torch.randn(c, 1, generator=g, device=gpu_device,
+                                                                    dtype=torch.float64)], -1).float().contiguous()
+    kern = DeviceHamiltonianMonteCarloKernel(post, step_size=4e-5, num_leapfrog_steps=4, seed=5)
+    assert lik.logp_ref is not None
+    st = kern.bootstrap(z)
+    accepted = 0
+    for _ in range(3):
+        z, st, tr = kern.one_step(z, st)
+        accepted += int(tr['is_accepted'].sum())
+        # float64 log-posterior at the chains' current positions
+        theta = torch.cat([z[:, :d + 1], torch.nn.functional.softplus(z[:, d + 1:])], -1)
+        ll64, _, _ = _reference_from_stats(r, theta)
+        t64 = theta.double()
+        prior = (-0.5 * (t64[:, :d + 1] / 10.0) ** 2 - math.log(10.0) - 0.5 * math.log(2 * math.pi)).sum(-1) \
+            + (math.log(2.0) - 0.5 * (t64[:, d + 1] / 10.0) ** 2 - math.log(10.0) - 0.5 * math.log(2 * math.pi))
+        fldj = torch.log(torch.sigmoid(z[:, d + 1].double()))
+        ref = ll64 + prior + fldj
+        rel, lvl = st['relative_log_prob'], st['log_prob_level']
+        assert float(rel.max()) == 0.0                             # re-levelled to the best chain
+        err = rel.double() + lvl - ref
+        assert float((err - err.mean()).abs().max()) <= 2e-2, float((err - err.mean()).abs().max())
+        assert float((st['target_log_prob'].double() - ref).abs().max()) <= 2.0      # absolute: float spacing
+        assert torch.equal(tr['target_log_prob'], st['target_log_prob'])
+    assert accepted > 0
+    lik.logp_ref = None
+
+
 def test_regression_10m_row_shards_add(nat, ws, regression_10m):
     """The outputs are likelihood-only sums, so two row shards -- packed separately, with their own
     column scales -- must add up to the full-data result (what the all-reduce over GPUs relies on)."""
@@ -242,6 +343,18 @@ def test_mixture_100m_rows(nat, ws, gpu_device):
     _close(a[0].double() + b[0].double(), lp, lp.abs(), what='mixture logp shards')
     scale = gr.abs().max(-1, keepdim=True).values.double() + 3e-2 * absg.max(0).values[None]
     _close(a[1].double() + b[1].double(), gr, scale, what='mixture grad shards')
+    # differences between nearby chains, relative to a level: |logp| ~ 3.5e8, floats 32 apart.  The kernel's own
+    # exp2 / log2 leave a common offset of a few nats (1e-8 of the total) that cancels between chains; what a
+    # Metropolis test sees is the spread.  (Parity unpinned for this family: the reference holds no fixture.)
+    th = torch.cat([(1.0 / k) * (1 + 1e-4 * torch.randn(64, k, generator=g, device=gpu_device)),
+                    locs + 1e-4 * torch.randn(64, k, generator=g, device=gpu_device),
+                    1 + 1e-4 * torch.randn(64, k, generator=g, device=gpu_device)], -1).contiguous()
+    ref64, _, _ = _mixture_float64(y, th[:6], k)
+    level = _level_of(nat, nat.gmm1d_logp_grad(y, th, k, ws, want_grad=False)[0])
+    for want_grad in (True, False):
+        rel, _ = nat.gmm1d_logp_grad(y, th, k, ws, want_grad=want_grad, logp_ref=level)
+        err = rel[:6].double() + level - ref64
+        assert float(err.abs().max()) <= 10.0 and float((err - err.mean()).abs().max()) <= 6e-2, err.tolist()
 
 
 def test_normal_100m_rows(nat, ws, gpu_device):
@@ -263,6 +376,18 @@ def test_normal_100m_rows(nat, ws, gpu_device):
     term = torch.stack([sa / sc ** 2, r2 / sc ** 3 + n / sc], -1)
     _close(lp, ref_lp, ref_lp.abs(), what='normal logp')
     _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='normal grad')
+    # differences between chains inside the posterior's width, relative to a level: |logp| ~ 2.5e8 (floats 16 apart)
+    mu_hat = s1 / n; sd_hat = torch.sqrt(s2 / n - mu_hat ** 2)
+    for cc, bar in ((64, 2e-2), (16, 0.5), (1, 0.5)):      # few chains: one float sum of ~400 rows per lane
+        th = torch.stack([mu_hat + 3e-4 * torch.randn(cc, generator=g, device=gpu_device, dtype=torch.float64),
+                          sd_hat * (1 + 1e-4 * torch.randn(cc, generator=g, device=gpu_device, dtype=torch.float64))],
+                         -1).float().contiguous()
+        mu, sc = th[:, 0].double(), th[:, 1].double()
+        ref64 = -0.5 * (s2 - 2 * mu * s1 + n * mu * mu) / sc ** 2 - n * torch.log(sc) - 0.5 * n * math.log(2 * math.pi)
+        level = _level_of(nat, nat.normal_iid_logp_grad(y, th, ws)[0])
+        rel, _ = nat.normal_iid_logp_grad(y, th, ws, logp_ref=level)
+        err = rel.double() + level - ref64
+        assert float(err.abs().max()) <= bar, (cc, float(err.abs().max()))
 
 
 def test_fullcov_mixture_1m_rows_shards_add(nat, ws, gpu_device):

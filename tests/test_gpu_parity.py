@@ -472,3 +472,37 @@ def test_gmm_fullcov(nat, ws, gpu_device, d, k, c, n):
     lp2, g2 = nat.gmm_fullcov_logp_grad(dev(Y, gpu_device), dev(theta, gpu_device), k, ws, want_grad=False)
     assert g2 is None
     np.testing.assert_array_equal(lp2.cpu().numpy(), lp.cpu().numpy())
+
+
+def test_logp_rebase_and_reference_level(nat, ws, gpu_device):
+    """bvi_logp_rebase: the largest finite stored log-density becomes 0, the level takes it (split over the row
+    shards), the absolute values come back, non-finite entries stay what they are; and a likelihood entry point
+    given that level returns log-densities relative to it (Normal family, against the absolute call)."""
+    lp = torch.tensor([-1.25e7, float('nan'), -1.2500003e7, float('-inf'), -1.3e7], device=gpu_device)
+    ref = torch.full((1,), 100.0, dtype=torch.float64, device=gpu_device)
+    before = lp.clone()
+    absolute = torch.empty_like(lp)
+    nat.logp_rebase(lp, 4, ref, absolute)
+    assert float(ref) == 100.0 + (-1.25e7) / 4
+    assert lp[0] == 0 and lp[2] == before[2] - before[0] and lp[4] == before[4] - before[0]
+    assert bool(torch.isnan(lp[1])) and lp[3] == float('-inf')
+    fin = torch.tensor([0, 2, 4], device=gpu_device)
+    assert torch.equal(absolute[fin], (before[fin].double() + 400.0).float())
+    # nothing finite: the level stays
+    bad = torch.tensor([float('nan'), float('-inf')], device=gpu_device)
+    nat.logp_rebase(bad, 1, ref)
+    assert float(ref) == 100.0 + (-1.25e7) / 4
+    # 1500 chains (more than one pass of the workgroup over the chains)
+    big = -1e6 - torch.arange(1500, device=gpu_device, dtype=torch.float32)
+    ref.zero_()
+    nat.logp_rebase(big, 1, ref)
+    assert float(ref) == -1e6 and big[0] == 0 and big[1499] == -1499
+    g = torch.Generator(device=gpu_device); g.manual_seed(2)
+    y = torch.empty(200_001, device=gpu_device).normal_(2.0, 1.5, generator=g)
+    th = torch.tensor([[2.0, 1.5], [2.1, 1.4], [1.9, 1.6]], device=gpu_device)
+    lp_abs, g_abs = nat.normal_iid_logp_grad(y, th, ws)
+    level = torch.tensor([float(lp_abs[0])], dtype=torch.float64, device=gpu_device)
+    lp_rel, g_rel = nat.normal_iid_logp_grad(y, th, ws, logp_ref=level)
+    assert torch.equal(g_abs, g_rel)
+    assert float((lp_rel.double() + level - lp_abs.double()).abs().max()) <= 0.5 * 2.0 ** -5   # half a float step at 3.7e5
+    assert abs(float(lp_rel[0])) <= 0.02
