@@ -74,6 +74,16 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
   }
 }
 
+// The level a typical row's log-density sits at, from the components' constants as the kernels hold them (floats):
+// the tallest component's constant minus D/2 (|u|^2 ~ D for a row of its own component).  The f16 kernel sums
+// log-densities relative to it, so that the float partial sums stay random-walk sized (|log p| ~ 4.5e7 at a
+// million rows of D = 32, where floats are 4 apart); fullcov_finalize adds n times the same float back in double.
+__device__ __forceinline__ float fullcov_row_level(const float* __restrict__ cst, int K, int D) {
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, cst[k]);
+  return isfinite(m) ? m - 0.5f * (float)D : 0.f;
+}
+
 template <int KQ>  // components per wave (K <= 4 * KQ)
 __global__ __launch_bounds__(256) void fullcov_kernel(const float* __restrict__ Y, int64_t n, int D, int K,
                                                       const float* __restrict__ Ainv,
@@ -339,7 +349,8 @@ __global__ __launch_bounds__(256) void fullcov_colstats_final(const double* __re
   cscale[col] = sc;
 }
 
-template <int KQ>  // components per wave (K <= FW * KQ)
+// GRAD = false (value only, what random-walk Metropolis asks for): no responsibilities, no raw sums
+template <int KQ, bool GRAD>  // components per wave (K <= FW * KQ)
 __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2))) void fullcov_f16_kernel(
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
@@ -414,7 +425,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int b = 0; b < 2; ++b) S2[q][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
-  float logp_acc = 0.f;
+  double logp_acc = 0.0;                      // running total of the rows' log-densities minus row_level
+  const float row_level = fullcov_row_level(cst + (int64_t)c * K, K, D);
 
   // staging: thread -> (row = tid / 8, columns 4 (tid % 8) .. + 3)
   const int srow = tid >> 3, sc4 = (tid & 7) * 4;
@@ -504,10 +516,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int k = 0; k < K; ++k) sm += __expf(al[k][row] - m);
       const float lse = m + __logf(sm);
       const bool valid = tile * FT + row < n;
-      if (wave == 0 && valid) logp_acc += lse;
+      if (wave == 0 && valid) logp_acc += (double)(lse - row_level);
       const float lsev = valid ? lse : INFINITY;
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
+      for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
         const int k = wave + FW * q;
         if (k < K) {
           // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
@@ -517,10 +529,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
     }
-    __syncthreads();
+    if (GRAD) __syncthreads();
     // ---- responsibilities and raw sums: w = sqrt(rho) u in two f16 pieces is both operand of S2 += W^T W ----
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) {
+    for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
       const int k = wave + FW * q;
       if (k < K) {
 #pragma unroll
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int Q = 1 + DP + DP * DP;
   float* out = partials + ((int64_t)blockIdx.x * C + c) * ((int64_t)K * Q + 1);
 #pragma unroll
-  for (int q = 0; q < KQ; ++q) {
+  for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
     const int k = wave + FW * q;
     if (k < K) {
       // S0: every lane of a 16-lane row holds the same rows; take one lane per row, add the 4 groups
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
   }
-  if (tid < FT) lpw[tid] = logp_acc;
+  if (tid < FT) lpw[tid] = (float)logp_acc;
   __syncthreads();
   if (tid == 0) {
     float s = 0.f;
@@ -603,7 +615,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // one block of 8 x DP threads per (chain, component): thread (j, ig) owns column j of the rows i = ig, ig + 8, ...
 __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restrict__ partials, int nb, int64_t n,
                                                            int D, int K, const float* __restrict__ theta,
-                                                           const float* __restrict__ Ainv, int C,
+                                                           const float* __restrict__ Ainv,
+                                                           const float* __restrict__ cst, int C,
                                                            float* __restrict__ logp, float* __restrict__ grad,
                                                            const double* __restrict__ ref) {
   constexpr int Q = 1 + DP + DP * DP, RG = DP / 8;
@@ -616,13 +629,17 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
   for (int r = 0; r < RG; ++r) col[r] = 0.0;
   for (int b = 0; b < nb; ++b) {
     const float* p = partials + ((int64_t)b * C + c) * stride + (int64_t)k * Q;
-    for (int r = 0; r < RG; ++r) col[r] += (double)p[1 + DP + (ig + 8 * r) * DP + j];
-    if (ig == 0) s1 += (double)p[1 + j];
+    if (grad) {                     // a value-only launch wrote the log-density partial only
+      for (int r = 0; r < RG; ++r) col[r] += (double)p[1 + DP + (ig + 8 * r) * DP + j];
+      if (ig == 0) s1 += (double)p[1 + j];
+    }
     if (threadIdx.x == 0) {
-      s0 += (double)p[0];
+      if (grad) s0 += (double)p[0];
       if (k == 0) lp += (double)partials[((int64_t)b * C + c) * stride + (int64_t)K * Q];
     }
   }
+  // the f16 kernel sums the rows' log-densities around a typical row's level (fullcov_row_level): back in double
+  if (cst && threadIdx.x == 0 && k == 0) lp += (double)n * (double)fullcov_row_level(cst + (int64_t)c * K, K, D);
   for (int r = 0; r < RG; ++r) {
     const int i = ig + 8 * r;
     S2[i][j] = col[r];
@@ -725,18 +742,20 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
                        bvec, blo, cst);
     BVI_HIP_CHECK_LAUNCH();
-    if (k <= FW)
-      hipLaunchKernelGGL(fullcov_f16_kernel<1>, grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,
-                         (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, c,
-                         partials);
-    else
-      hipLaunchKernelGGL(fullcov_f16_kernel<2>, grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,
-                         (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, c,
-                         partials);
+#define BVI_FC16(KQ, GRAD)                                                                                          \
+  hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,           \
+                     (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
+                     c, partials)
+    if (k <= FW) {
+      if (grad) BVI_FC16(1, true); else BVI_FC16(1, false);
+    } else {
+      if (grad) BVI_FC16(2, true); else BVI_FC16(2, false);
+    }
+#undef BVI_FC16
   }
   BVI_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(8 * DP), 0, s, (const float*)partials, nb, n, d, k, theta,
-                     (const float*)Ainv, c, logp, grad, logp_ref);
+                     (const float*)Ainv, use_f32 ? (const float*)nullptr : (const float*)cst, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

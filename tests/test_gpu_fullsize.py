@@ -413,6 +413,29 @@ def test_fullcov_mixture_1m_rows_shards_add(nat, ws, gpu_device):
     for lo, hi in ((0, k), (k, k + k * d), (k + k * d, th.shape[1])):
         scale = gr[:, lo:hi].abs().max(-1, keepdim=True).values.double()
         _close((a[1].double() + b[1].double())[:, lo:hi], gr[:, lo:hi], scale, rtol=3 * RTOL, what='fullcov grad shards')
+    # the value-only launch (no responsibilities, no raw sums) returns the same log-densities
+    lpv, none = nat.gmm_fullcov_logp_grad(Y, th, k, ws, want_grad=False)
+    assert none is None and torch.equal(lp, lpv)
+    # float64 evaluation of the first 200k rows for two chains; then differences relative to a level
+    # (|logp| ~ 1e7 per 200k rows; parity unpinned for this family: the reference holds no fixture for it)
+    m = 200_000
+    Ym = Y[:m].contiguous()
+    t64 = th[:2].double()
+    w = t64[:, :k]; mu = t64[:, k:k + k * d].reshape(2, k, d); Lc = torch.tril(t64[:, k + k * d:].reshape(2, k, d, d))
+    ref64 = torch.zeros(2, dtype=torch.float64, device=gpu_device)
+    for s0 in range(0, m, 20_000):
+        yc = Ym[s0:s0 + 20_000].double()
+        diff = yc[None, None] - mu[:, :, None]                                   # [2, k, rows, d]
+        z = torch.linalg.solve_triangular(Lc, diff.transpose(-1, -2), upper=False)   # [2, k, d, rows]
+        e = torch.log(w / w.sum(-1, keepdim=True))[..., None] - torch.log(torch.diagonal(Lc, dim1=-2, dim2=-1)).sum(-1)[..., None] \
+            - 0.5 * d * math.log(2 * math.pi) - 0.5 * (z * z).sum(-2)
+        ref64 += torch.logsumexp(e, 1).sum(-1)
+    lpm, _ = nat.gmm_fullcov_logp_grad(Ym, th[:2].contiguous(), k, ws)
+    _close(lpm, ref64, ref64.abs(), what='fullcov logp 200k rows')
+    level = _level_of(nat, lpm)
+    rel, _ = nat.gmm_fullcov_logp_grad(Ym, th[:2].contiguous(), k, ws, logp_ref=level)
+    err = rel.double() + level - ref64
+    assert float(err.abs().max()) <= 0.5, err.tolist()
 
 
 # ---- BASELINE.json configs[4]: ELBO gradients on the 10M x 64 regression with 256 Monte-Carlo samples ----

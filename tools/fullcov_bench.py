@@ -26,3 +26,13 @@ ts.sort()
 fl = 6.0 * n * c * k * d * d
 print('fullcov N=%d D=%d K=%d C=%d: median %.2f ms -> %.1f TFLOP/s (6 N C K D^2), %.1f K grad-evals/s, finite=%s'
       % (n, d, k, c, ts[2], fl / ts[2] / 1e9, c / ts[2], bool(torch.isfinite(lp).all())))
+for _ in range(2):
+    nat.gmm_fullcov_logp_grad(Y, th, k, ws, want_grad=False)
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); lpv, _ = nat.gmm_fullcov_logp_grad(Y, th, k, ws, want_grad=False); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+ts.sort()
+print('fullcov N=%d D=%d K=%d C=%d value only: median %.2f ms, same log-densities: %s' % (n, d, k, c, ts[2], bool(torch.equal(lp, lpv))))
