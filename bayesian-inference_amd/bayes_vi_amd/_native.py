@@ -20,7 +20,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 103     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 104     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -31,7 +31,7 @@ class ParamBlock(ctypes.Structure):
 
 NUTS_ACTIVE, NUTS_BUILDING, NUTS_TURNED, NUTS_DIVERGED, NUTS_MOVED, NUTS_FORWARD = 1, 2, 4, 8, 16, 32
 _NUTS_FLOAT_ARRAYS = ('z', 'lp', 'grad', 'q', 'p', 'gq', 'lpq', 'ql', 'pl', 'gl', 'qr', 'pr', 'gr', 'sub_q', 'sub_g',
-                      'sub_lp', 'ck_q', 'ck_p', 'h0', 'log_w', 'sub_log_w', 'sum_acc', 'log_u_sub', 'se')
+                      'sub_lp', 'ck_q', 'ck_p', 'h0', 'log_w', 'sub_log_w', 'sum_acc', 'log_u_sub', 'se', 'energy', 'sub_energy')
 _NUTS_INT_ARRAYS = ('n_leap', 'leaf_ctr', 'flags')
 
 
@@ -100,7 +100,7 @@ def lib():
         l.bvi_hmc_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, vp, i32, i32, u64, u64, i32,
                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_nuts_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, vp, i32, f32, i32, u64, u64, i32,
-                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_rwm_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, i32, u64, u64, i32,
                                     vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]

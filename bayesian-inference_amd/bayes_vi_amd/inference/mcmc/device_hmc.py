@@ -247,7 +247,7 @@ class FusedNoUTurnSamplerKernel:
     def _launch(self, z, g, lp, n_transitions, evaluate_initial, seed, outs=None):
         fam, X, y, n, d, k = self.family
         ptr = _native._ptr
-        outs = outs if outs is not None else (None,) * 6
+        outs = outs if outs is not None else (None,) * 7
         _native.check(_native.lib().bvi_nuts_fused(
             fam, ptr(X), ptr(y), n, d, k, self.blocks, self.nb, z.shape[0], self.step_size, None,
             self.max_tree_depth, self.max_energy_diff, n_transitions, seed, self.transition,
@@ -268,15 +268,15 @@ class FusedNoUTurnSamplerKernel:
         g = state['grad'].clone()
         c, pu = z.shape
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=z.device)
-        zs, lps, lrs = f(n, c, pu), f(n, c), f(n, c)
+        zs, lps, lrs, energy = f(n, c, pu), f(n, c), f(n, c), f(n, c)
         moved = torch.empty(n, c, dtype=torch.uint8, device=z.device)
         div = torch.empty(n, c, dtype=torch.uint8, device=z.device)
         leaps = torch.empty(n, c, dtype=torch.int32, device=z.device)
         seed = self.seed if generator is None else (self.seed ^ int(generator.initial_seed()))
-        self._launch(z, g, lp, n, False, seed, (zs, lps, moved, lrs, leaps, div))
+        self._launch(z, g, lp, n, False, seed, (zs, lps, moved, lrs, leaps, div, energy))
         traces = {'is_accepted': moved.to(torch.bool), 'target_log_prob': lps, 'log_accept_ratio': lrs,
                   'step_size': torch.full((n,), self.step_size, dtype=z.dtype),
-                  'leapfrogs_taken': leaps.to(torch.int64), 'has_divergence': div.to(torch.bool), 'energy': -lps}
+                  'leapfrogs_taken': leaps.to(torch.int64), 'has_divergence': div.to(torch.bool), 'energy': energy}
         return zs, z, {'target_log_prob': lp, 'grad': g}, traces
 
     def one_step(self, z, state, generator=None):
@@ -366,7 +366,8 @@ class BatchedDeviceNoUTurnSamplerKernel:
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
             i = lambda *s: torch.empty(*s, dtype=torch.int32, device=device)
             b = {n: f(c, pu) for n in ('q', 'p', 'gq', 'ql', 'pl', 'gl', 'qr', 'pr', 'gr', 'sub_q', 'sub_g')}
-            b.update({n: f(c) for n in ('lpq', 'sub_lp', 'h0', 'log_w', 'sub_log_w', 'sum_acc', 'log_u_sub', 'se')})
+            b.update({n: f(c) for n in ('lpq', 'sub_lp', 'h0', 'log_w', 'sub_log_w', 'sum_acc', 'log_u_sub', 'se', 'energy',
+                                         'sub_energy')})
             b.update({n: i(c) for n in ('n_leap', 'leaf_ctr', 'flags')})
             b['ck_q'], b['ck_p'] = f(self.max_tree_depth + 1, c, pu), f(self.max_tree_depth + 1, c, pu)
             b['theta'] = f(c, self.posterior.n_constrained)
@@ -424,11 +425,12 @@ class BatchedDeviceNoUTurnSamplerKernel:
         fl = b['flags']
         n_leap = b['n_leap'].to(torch.int64)
         lr = torch.log(torch.clamp(b['sum_acc'] / torch.clamp(n_leap, min=1).to(z.dtype), min=1e-30))
+        energy = self.posterior.absolute(b['energy'])      # stored relative to the same level as lp
         lp_abs = torch.empty_like(lp)
         self.posterior.rebase(lp, lp_abs)   # lp stays relative to a level that follows the chains
         trace = {'is_accepted': (fl & _native.NUTS_MOVED) != 0, 'target_log_prob': lp_abs, 'log_accept_ratio': lr,
                  'step_size': torch.full((), self.step_size, dtype=z.dtype), 'leapfrogs_taken': n_leap,
-                 'has_divergence': (fl & _native.NUTS_DIVERGED) != 0, 'energy': -lp_abs}
+                 'has_divergence': (fl & _native.NUTS_DIVERGED) != 0, 'energy': energy}
         return z, dict(self.posterior.log_prob_state(lp, lp_abs), grad=g), trace
 
 

@@ -145,6 +145,9 @@ class NoUTurnSamplerKernel:
         qr, pr, gr = z.clone(), p0.clone(), g0.clone()
         # current sample and its cached log prob / gradient
         qs, lps, gs = z.clone(), lp0.clone(), g0.clone()
+        # log-density minus kinetic energy at the selected point: what tfp's NoUTurnSampler reports as `energy`
+        # (compute_hamiltonian of the candidate state; transition_kernels.py:261 traces it)
+        es = -h0
         log_w = torch.zeros(C, device=dev, dtype=dt)              # log sum of weights exp(h0 - h)
         active = torch.ones(C, dtype=torch.bool, device=dev)
         diverged = torch.zeros(C, dtype=torch.bool, device=dev)
@@ -165,7 +168,7 @@ class NoUTurnSamplerKernel:
             g = torch.where(go_right[:, None], gr, gl)
             sub_ok = active.clone()                               # chains still building this subtree
             sub_log_w = torch.full((C,), -math.inf, device=dev, dtype=dt)
-            sub_q, sub_lp, sub_g = qs.clone(), lps.clone(), gs.clone()
+            sub_q, sub_lp, sub_g, sub_e = qs.clone(), lps.clone(), gs.clone(), es.clone()
             turning_sub = torch.zeros(C, dtype=torch.bool, device=dev)
             for leaf in range(2 ** depth):
                 for _ in range(self.unrolled):
@@ -187,6 +190,7 @@ class NoUTurnSamplerKernel:
                 take = ok & (torch.log(rnd(C)) < lw - new_sub_log_w)
                 sub_q = torch.where(take[:, None], q, sub_q)
                 sub_lp = torch.where(take, lp, sub_lp)
+                sub_e = torch.where(take, -h, sub_e)
                 sub_g = torch.where(take[:, None], g, sub_g)
                 sub_log_w = torch.where(ok, new_sub_log_w, sub_log_w)
                 # U-turn checks inside the subtree via checkpoints of left ends
@@ -218,6 +222,7 @@ class NoUTurnSamplerKernel:
             accept_sub = complete & (torch.log(rnd(C)) < sub_log_w - log_w)     # biased progressive sampling
             qs = torch.where(accept_sub[:, None], sub_q, qs)
             lps = torch.where(accept_sub, sub_lp, lps)
+            es = torch.where(accept_sub, sub_e, es)
             gs = torch.where(accept_sub[:, None], sub_g, gs)
             moved |= accept_sub
             log_w = torch.where(complete, torch.logaddexp(log_w, sub_log_w), log_w)
@@ -229,7 +234,7 @@ class NoUTurnSamplerKernel:
         new_state = {'target_log_prob': lps, 'grad': gs}
         trace = {'is_accepted': moved, 'target_log_prob': lps, 'log_accept_ratio': log_accept_ratio,
                  'step_size': torch.full((), eps, dtype=dt), 'leapfrogs_taken': n_leap,
-                 'has_divergence': diverged, 'energy': -lps}
+                 'has_divergence': diverged, 'energy': es}
         return qs, new_state, trace
 
 

@@ -59,6 +59,7 @@ struct FusedArgs {
   float max_energy_diff;
   int* leap_out;
   unsigned char* div_out;
+  float* energy_out;
 };
 
 __device__ __forceinline__ float log_add_exp(float a, float b) {
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
         p0 = v[lane & 3];
       }
       const float h0 = -lp + wave_sum(0.5f * p0 * p0);
+      float energy = -h0;       // log-density minus kinetic energy at the selected point (tfp's kernel_results.energy)
       float ql = zj, pl = p0, gl = gj, qr = zj, pr = p0, gr = gj;     // trajectory ends (left = backward in time)
       float log_w = 0.f, sum_acc = 0.f;
       int n_leap = 0, leaf_ctr = 0;
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
         const float log_u_sub = logf(u01(rd.y));
         const float se = go_right ? eps : -eps;
         float q = go_right ? qr : ql, p = go_right ? pr : pl, g = go_right ? gr : gl;
-        float sub_log_w = -INFINITY, sub_q = zj, sub_g = gj, sub_lp = lp;
+        float sub_log_w = -INFINITY, sub_q = zj, sub_g = gj, sub_lp = lp, sub_e = energy;
         bool sub_ok = true, turn_sub = false;
         const int n_leaves = 1 << depth;
         for (int leaf = 0; leaf < n_leaves; ++leaf) {
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
             sub_q = q;
             sub_g = g;
             sub_lp = lpq;
+            sub_e = -(dh + h0);
           }
           if (ok) sub_log_w = new_w;
           // U-turn checks inside the subtree against checkpoints of the left ends of its sub-subtrees:
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
           zj = sub_q;
           gj = sub_g;
           lp = sub_lp;
+          energy = sub_e;
           moved = true;
         }
         if (complete) log_w = log_add_exp(log_w, sub_log_w);
@@ -452,6 +456,7 @@ __global__ __launch_bounds__(256) void hmc_fused_kernel(Blocks bl, FusedArgs a) 
           if (a.lr_out) a.lr_out[o] = logf(fmaxf(sum_acc / (float)(n_leap > 0 ? n_leap : 1), 1e-30f));
           if (a.leap_out) a.leap_out[o] = n_leap;
           if (a.div_out) a.div_out[o] = diverged ? 1 : 0;
+          if (a.energy_out) a.energy_out[o] = energy;
         }
       }
     }
@@ -550,7 +555,7 @@ extern "C" int bvi_nuts_fused(int family, const float* X, const float* y, int64_
                               int n_transitions, uint64_t seed, uint64_t first_step, int evaluate_initial, float* z,
                               float* grad_z, float* lp, float* z_out, float* lp_out, unsigned char* moved_out,
                               float* log_accept_out, int* leapfrogs_out, unsigned char* diverged_out,
-                              void* stream) {
+                              float* energy_out, void* stream) {
   if (max_tree_depth < 1 || max_tree_depth > kMaxDepth || !(max_energy_diff > 0.f)) return BVI_ERR_ARG;
   FusedArgs a = {};
   a.C = n_chains; a.T = n_transitions; a.L = 1;
@@ -558,6 +563,6 @@ extern "C" int bvi_nuts_fused(int family, const float* X, const float* y, int64_
   a.evaluate_initial = evaluate_initial; a.z = z; a.g = grad_z; a.lp = lp;
   a.z_out = z_out; a.lp_out = lp_out; a.acc_out = moved_out; a.lr_out = log_accept_out;
   a.max_depth = max_tree_depth; a.max_energy_diff = max_energy_diff; a.leap_out = leapfrogs_out;
-  a.div_out = diverged_out;
+  a.div_out = diverged_out; a.energy_out = energy_out;
   return run_fused(1, family, X, y, n, d, k, blocks, n_blocks, a, stream);
 }

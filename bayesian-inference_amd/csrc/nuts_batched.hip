@@ -57,6 +57,7 @@ __global__ __launch_bounds__(1024) void nuts_begin_kernel(bvi_nuts_state s, uint
   ke = block_reduce<false>(ke, red);
   if (lane == 0) {
     s.h0[c] = -s.lp[c] + ke;
+    s.energy[c] = s.lp[c] - ke;           // of the selected point: the initial one until a subtree replaces it
     s.log_w[c] = 0.f;
     s.sum_acc[c] = 0.f;
     s.n_leap[c] = 0;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(1024) void nuts_subtree_begin_kernel(bvi_nuts_state
     s.log_u_sub[c] = logf(u01(rd.y));
     s.sub_log_w[c] = -INFINITY;
     s.sub_lp[c] = s.lp[c];
+    s.sub_energy[c] = s.energy[c];
     s.flags[c] = (fl & ~(F_SUB_OK | F_TURN | F_RIGHT)) | (active ? F_SUB_OK : 0) | (go_right ? F_RIGHT : 0);
   }
 }
@@ -118,7 +120,10 @@ __global__ __launch_bounds__(1024) void nuts_leaf_kernel(bvi_nuts_state s, uint6
       s.sub_q[o + j] = s.q[o + j];
       s.sub_g[o + j] = s.gq[o + j];
     }
-    if (lane == 0) s.sub_lp[c] = lpq;
+    if (lane == 0) {
+      s.sub_lp[c] = lpq;
+      s.sub_energy[c] = lpq - ke;
+    }
   }
   // U-turn checks against the checkpoints of the left ends of the sub-subtrees this leaf completes
   bool turn = fl & F_TURN;
@@ -172,7 +177,10 @@ __global__ __launch_bounds__(1024) void nuts_subtree_end_kernel(bvi_nuts_state s
   const bool turning = nb_turning(s.ql + o, s.pl + o, s.qr + o, s.pr + o, Pu, red);
   const bool active = complete && !turning;
   if (lane == 0) {
-    if (accept) s.lp[c] = s.sub_lp[c];
+    if (accept) {
+      s.lp[c] = s.sub_lp[c];
+      s.energy[c] = s.sub_energy[c];
+    }
     if (complete) s.log_w[c] = nb_log_add_exp(log_w, sub_w);
     fl = (fl & ~(F_ACTIVE | F_SUB_OK)) | (active ? F_ACTIVE : 0) | (accept ? F_MOVED : 0);
     s.flags[c] = fl;
@@ -189,7 +197,7 @@ int check_state(const bvi_nuts_state* s) {
     return BVI_ERR_ARG;
   const void* ptrs[] = {s->z, s->lp, s->grad, s->q, s->p, s->gq, s->lpq, s->ql, s->pl, s->gl, s->qr, s->pr, s->gr,
                         s->sub_q, s->sub_g, s->sub_lp, s->ck_q, s->ck_p, s->h0, s->log_w, s->sub_log_w, s->sum_acc,
-                        s->log_u_sub, s->se, s->n_leap, s->leaf_ctr, s->flags};
+                        s->log_u_sub, s->se, s->energy, s->sub_energy, s->n_leap, s->leaf_ctr, s->flags};
   for (const void* p : ptrs)
     if (!p) return BVI_ERR_ARG;
   return BVI_OK;

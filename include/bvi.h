@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 103
+#define BVI_VERSION 104
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -281,6 +281,8 @@ typedef struct bvi_nuts_state {
   float *sub_q, *sub_g, *sub_lp;        /* candidate of the subtree [C,Pu] x2, [C] */
   float *ck_q, *ck_p;                   /* U-turn checkpoints [max_tree_depth+1, C, Pu] */
   float *h0, *log_w, *sub_log_w, *sum_acc, *log_u_sub, *se;   /* [C]; se = signed step size of this subtree, 0 = frozen */
+  float *energy, *sub_energy;           /* [C]; log density minus kinetic energy at the selected point / the subtree's
+                                           candidate: tfp's kernel_results.energy (out) */
   int *n_leap, *leaf_ctr, *flags;       /* [C]; flags = OR of BVI_NUTS_* */
 } bvi_nuts_state;
 int bvi_nuts_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, void* stream);
@@ -321,13 +323,15 @@ int bvi_hmc_fused(int family, const float* X, const float* y, int64_t n, int d, 
  * words 0, 1 of block `depth`, stream 2; multinomial uniform of the n-th leapfrog: word 0 of block n,
  * stream 3).  Per-transition outputs, all optional: z_out [T,C,Pu], lp_out [T,C], moved_out [T,C] (the
  * sample left the initial point), log_accept_out [T,C] (log of the mean min(1, exp(-dH)) over the
- * trajectory: what step-size adaptation consumes), leapfrogs_out [T,C], diverged_out [T,C]. */
+ * trajectory: what step-size adaptation consumes), leapfrogs_out [T,C], diverged_out [T,C], energy_out [T,C]
+ * (log-density minus kinetic energy at the selected point: tfp's kernel_results.energy, which
+ * transition_kernels.py:261 traces). */
 int bvi_nuts_fused(int family, const float* X, const float* y, int64_t n, int d, int k,
                    const bvi_param_block* blocks, int n_blocks, int n_chains, float step_size,
                    const float* step_sizes, int max_tree_depth, float max_energy_diff, int n_transitions,
                    uint64_t seed, uint64_t first_step, int evaluate_initial, float* z, float* grad_z, float* lp,
                    float* z_out, float* lp_out, unsigned char* moved_out, float* log_accept_out,
-                   int* leapfrogs_out, unsigned char* diverged_out, void* stream);
+                   int* leapfrogs_out, unsigned char* diverged_out, float* energy_out, void* stream);
 
 /* Random-walk Metropolis in the same form: z' = z + proposal_scale * N(0, I), accepted with probability
  * min(1, pi(z') / pi(z)); replaces tfp.mcmc.RandomWalkMetropolis.one_step with its default proposal

@@ -47,6 +47,7 @@ def nuts_step(value_and_grad, z, lp, g, chain, seed, step, step_size, max_tree_d
     ql, pl, gl = z.copy(), p0.copy(), g.copy()
     qr, pr, gr = z.copy(), p0.copy(), g.copy()
     zs, lps, gs = z.copy(), lp, g.copy()
+    energy = -h0          # tfp's kernel_results.energy: log-density minus kinetic energy at the selected point
     log_w, sum_acc, n_leap, leaf_ctr = 0.0, 0.0, 0, 0
     active, diverged, moved = True, False, False
     margins = []
@@ -58,7 +59,7 @@ def nuts_step(value_and_grad, z, lp, g, chain, seed, step, step_size, max_tree_d
         log_u_sub = np.log(float(philox.u01(dirs[depth, 1])))
         se = step_size if go_right else -step_size
         q, p, gq = (qr.copy(), pr.copy(), gr.copy()) if go_right else (ql.copy(), pl.copy(), gl.copy())
-        sub_log_w, sub_q, sub_g, sub_lp = -np.inf, zs.copy(), gs.copy(), lps
+        sub_log_w, sub_q, sub_g, sub_lp, sub_e = -np.inf, zs.copy(), gs.copy(), lps, energy
         sub_ok, turn_sub = True, False
         for leaf in range(2 ** depth):
             p = p + 0.5 * se * gq
@@ -80,7 +81,7 @@ def nuts_step(value_and_grad, z, lp, g, chain, seed, step, step_size, max_tree_d
             if ok:
                 margins.append(abs(log_ul - (lw - new_w)))
                 if log_ul < lw - new_w:
-                    sub_q, sub_g, sub_lp = q.copy(), gq.copy(), lpq
+                    sub_q, sub_g, sub_lp, sub_e = q.copy(), gq.copy(), lpq, lpq - 0.5 * p @ p
                 sub_log_w = new_w
             hi = bin(leaf >> 1).count('1')
             if leaf % 2 == 0:
@@ -106,11 +107,12 @@ def nuts_step(value_and_grad, z, lp, g, chain, seed, step, step_size, max_tree_d
         if complete:
             margins.append(abs(log_u_sub - (sub_log_w - log_w)))
             if log_u_sub < sub_log_w - log_w:
-                zs, gs, lps, moved = sub_q, sub_g, sub_lp, True
+                zs, gs, lps, moved, energy = sub_q, sub_g, sub_lp, True, sub_e
             log_w = _log_add_exp(log_w, sub_log_w)
             dq = qr - ql
             margins.append(min(abs(dq @ pl), abs(dq @ pr)) / (np.abs(dq) @ np.abs(pl) + 1e-300))
         active = complete and not _turning(ql, pl, qr, pr)
         depth += 1
     return dict(z=zs, lp=lps, g=gs, moved=moved, log_accept_ratio=float(np.log(max(sum_acc / max(n_leap, 1), 1e-30))),
-                leapfrogs=n_leap, diverged=bool(diverged), margin=min(margins) if margins else np.inf)
+                leapfrogs=n_leap, diverged=bool(diverged), margin=min(margins) if margins else np.inf,
+                energy=float(energy))

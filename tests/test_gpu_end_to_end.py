@@ -496,6 +496,7 @@ def test_fused_nuts_kernel_follows_oracle_transition_by_transition(bvi, gpu_devi
         zs, zf, stf, tr = kern.many_steps(zt, st, T)
         zs = zs.cpu().numpy(); lps = tr['target_log_prob'].cpu().numpy()
         leaps = tr['leapfrogs_taken'].cpu().numpy(); moved = tr['is_accepted'].cpu().numpy()
+        energies = tr['energy'].cpu().numpy()
         lrs = tr['log_accept_ratio'].cpu().numpy()
         assert not tr['has_divergence'].any()
         assert leaps.min() >= 1 and leaps.max() <= 15, name
@@ -512,6 +513,8 @@ def test_fused_nuts_kernel_follows_oracle_transition_by_transition(bvi, gpu_devi
                     assert out['moved'] == bool(moved[t, ch]), (name, ch, t)
                     np.testing.assert_allclose(zs[t, ch], out['z'], rtol=2e-4, atol=2e-4)
                     assert abs(lrs[t, ch] - out['log_accept_ratio']) < 5e-3
+                    # log density minus kinetic energy at the selected point (tfp's kernel_results.energy)
+                    assert abs(energies[t, ch] - out['energy']) <= 2e-5 * abs(out['energy']) + 5e-3, (name, ch, t)
                     compared += 1
                 prev = zs[t, ch].astype(np.float64)
         assert compared > 0.6 * c * T, (name, compared)
@@ -541,6 +544,7 @@ def test_batched_device_nuts_follows_oracle_transition_by_transition(bvi, gpu_de
             zt, st, tr = kern.one_step(zt, st)
             znew = zt.cpu().numpy()
             leaps = tr['leapfrogs_taken'].cpu().numpy(); moved = tr['is_accepted'].cpu().numpy()
+            energies = tr['energy'].cpu().numpy()
             lrs = tr['log_accept_ratio'].cpu().numpy()
             assert not tr['has_divergence'].any()
             lp_new, g_new = f(znew.astype(np.float64))
@@ -555,6 +559,7 @@ def test_batched_device_nuts_follows_oracle_transition_by_transition(bvi, gpu_de
                     assert out['moved'] == bool(moved[ch]), (name, ch, t)
                     np.testing.assert_allclose(znew[ch], out['z'], rtol=2e-4, atol=2e-4)
                     assert abs(lrs[ch] - out['log_accept_ratio']) < 5e-3
+                    assert abs(energies[ch] - out['energy']) <= 2e-5 * abs(out['energy']) + 5e-3, (name, ch, t)
                     compared += 1
                     sizes.add(int(leaps[ch]))
         assert compared > 0.6 * c * T, (name, compared)

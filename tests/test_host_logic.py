@@ -259,6 +259,7 @@ def test_posterior_moments_match_reference_table(kernel_name):
     assert 0.15 < float(acc) <= 1.0
     if kernel_name == 'nuts':
         assert int(tr['leapfrogs_taken'].max()) <= 31 and not bool(tr['has_divergence'].any())
+        assert bool((tr['energy'] <= tr['target_log_prob'] + 1e-4).all())    # log density minus kinetic energy
 
 
 def test_linreg_nuts_matches_reference_table():

@@ -338,13 +338,17 @@ def test_oracle_nuts_reproduces_exact_posterior_moments():
     f = lambda q: spec.log_post_unconstrained(q)
     z = np.array([7.0, 1.0])
     lp, g = f(z[None]); lp, g = float(lp[0]), g[0]
-    draws, leaps = [], []
+    draws, leaps, kin = [], [], []
     for t in range(2500):
         out = nuts.nuts_step(f, z, lp, g, chain=0, seed=11, step=t, step_size=0.35, max_tree_depth=5)
         z, lp, g = out['z'], out['lp'], out['g']
+        assert out['energy'] <= lp + 1e-12            # log density minus a kinetic energy
         if t >= 300:
-            draws.append(z.copy()); leaps.append(out['leapfrogs'])
+            draws.append(z.copy()); leaps.append(out['leapfrogs']); kin.append(lp - out['energy'])
     draws = np.array(draws)
+    # `energy` is the log density minus the kinetic energy at the selected point; at stationarity the momentum
+    # there is N(0, I), so the kinetic part averages P/2 = 1
+    assert abs(np.mean(kin) - 1.0) < 0.1, np.mean(kin)
     loc, scale = draws[:, 0], np.log1p(np.exp(draws[:, 1]))
     m, s = y.mean(), y.std(ddof=1)
     L, S = np.meshgrid(np.linspace(m - 6 * s / math.sqrt(20), m + 6 * s / math.sqrt(20), 241),
