@@ -273,6 +273,13 @@ __device__ __forceinline__ void fc_split_pair(float q0, float q1, unsigned& hi, 
       : "v"(q0), "v"(q1));
 }
 
+// step S (0..3) of the sum over the 16 lanes of a DPP row (after all four: the result in every lane)
+template <int S>
+__device__ __forceinline__ float row16_sum_step(float v) {
+  constexpr int ctrl = S == 0 ? 0xB1 : S == 1 ? 0x4E : S == 2 ? 0x124 : 0x128;
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true));
+}
+
 // sum over the 16 lanes of a DPP row, result in every lane
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -472,36 +479,64 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned char* yh = ybuf[buf][0];
     const unsigned char* yl = ybuf[buf][1];
     // ---- GEMM1: u = A (y - mu) for the wave's components, rows 4 g + i of each 16-row tile in registers ----
-    f32x4 u[KQ][4][2];
+    // Software-pipelined over the 4 KQ (row tile, component) groups: while the matrix pipe runs the 8 MFMAs of group
+    // j + 1 (two dependent chains of four, interleaved), the vector ALU turns the accumulators of group j into u,
+    // |u|^2 (4 fma per MFMA slot) and its sum over the 16 lanes of a row (4 DPP adds per slot).  Written as one MFMA
+    // + one chunk of vector work per slot with a scheduling barrier after each, because left to itself the
+    // compiler emits the eight MFMAs back to back and the 40 vector instructions after them.
+    f32x4 u[GRAD ? KQ : 1][4][2];
+    {
+      constexpr int NG = 4 * KQ;
+      f16x8 fh[2], fl[2];                    // A operands of the row tile being multiplied / the next one
+      f32x4 zc[2], zn[2];
+      auto load_tile = [&](int rt, int slot) {
+        const int off = (16 * rt + ln) * 64 + ((g ^ swz(16 * rt + ln)) << 4);
+        fh[slot] = *reinterpret_cast<const f16x8*>(yh + off);
+        fl[slot] = *reinterpret_cast<const f16x8*>(yl + off);
+      };
+      // MFMA m (0..7) of a group: chain nt = m & 1, product m >> 1 of (yh a1, yl a1, yh a2, yh a3), on top of -t b_hi
+      auto mfma_step = [&](int q, int slot, int m, f32x4 (&z)[2]) {
+        const int nt = m & 1, pr = m >> 1;
+        const f16x8 av = pr <= 1 ? a1[q][nt] : (pr == 2 ? a2[q][nt] : a3[q][nt]);
+        const f16x8 yv = pr == 1 ? fl[slot] : fh[slot];
+        const f32x4 c0 = {zb[q][nt], zb[q][nt], zb[q][nt], zb[q][nt]};
+        z[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yv, av, pr == 0 ? c0 : z[nt], 0, 0, 0);
+      };
+      load_tile(0, 0);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int off = (16 * rt + ln) * 64 + ((g ^ swz(16 * rt + ln)) << 4);
-      const f16x8 fh = *reinterpret_cast<const f16x8*>(yh + off);
-      const f16x8 fl = *reinterpret_cast<const f16x8*>(yl + off);
+      for (int m = 0; m < 8; ++m) mfma_step(0, 0, m, zc);
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        f32x4 nrm = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NG; ++j) {
+        const int rt = j / KQ, q = j % KQ;
+        const int jn = j + 1, rtn = jn / KQ, qn = jn % KQ;
+        if (jn < NG && qn == 0) load_tile(rtn, rtn & 1);
+        f32x4 nrm;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          f32x4 z = {zb[q][nt], zb[q][nt], zb[q][nt], zb[q][nt]};    // accumulate on top of -t b_hi
-          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a1[q][nt], z, 0, 0, 0);
-          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, a1[q][nt], z, 0, 0, 0);
-          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a2[q][nt], z, 0, 0, 0);
-          z = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, a3[q][nt], z, 0, 0, 0);
+        for (int m = 0; m < 8; ++m) {
+          if (jn < NG) mfma_step(qn, rtn & 1, m, zn);
+          if (m < 4) {
+            const float u0 = fmaf(zc[0][m], inv_t[q], -bl[q][0]);
+            const float u1 = fmaf(zc[1][m], inv_t[q], -bl[q][1]);
+            if (GRAD) {
+              u[GRAD ? q : 0][rt][0][m] = u0;
+              u[GRAD ? q : 0][rt][1][m] = u1;
+            }
+            nrm[m] = fmaf(u1, u1, u0 * u0);
+          } else {
+            // |u|^2 of row 16 rt + 4 g + i: sum over the 16 lanes that hold its output dims, one butterfly step
+            // of all four rows per slot (independent instructions: no wait states between them)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float uu = fmaf(z[i], inv_t[q], -bl[q][nt]);
-            u[q][rt][nt][i] = uu;
-            nrm[i] = fmaf(uu, uu, nrm[i]);
+            for (int i = 0; i < 4; ++i)
+              nrm[i] = m == 4 ? row16_sum_step<0>(nrm[i]) : m == 5 ? row16_sum_step<1>(nrm[i])
+                     : m == 6 ? row16_sum_step<2>(nrm[i]) : row16_sum_step<3>(nrm[i]);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        // |u|^2 of row 16 rt + 4 g + i: sum over the 16 lanes that hold its output dims
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nrm[i] = row16_sum(nrm[i]);
         if (ln == 0) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) al[wave + FW * q][16 * rt + 4 * g + i] = cq[q] - 0.5f * nrm[i];
         }
+        if (jn < NG) { zc[0] = zn[0]; zc[1] = zn[1]; }
       }
     }
     __syncthreads();
@@ -510,10 +545,20 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       // sqrt(rho_ik) = exp((a_ik - lse) / 2) for this wave's components, once per (row, component) instead of once
       // per lane that needs it
       const int row = lane;
+      // all FW KQ loads in flight at once (a loop over the run-time K waits for one LDS round trip per component:
+      // 2 x 16 of them were half of the tile's time)
+      float av[FW * KQ];
+#pragma unroll
+      for (int k = 0; k < FW * KQ; ++k) av[k] = al[k][row];
       float m = -INFINITY;
-      for (int k = 0; k < K; ++k) m = fmaxf(m, al[k][row]);
+#pragma unroll
+      for (int k = 0; k < FW * KQ; ++k) {
+        av[k] = k < K ? av[k] : -INFINITY;
+        m = fmaxf(m, av[k]);
+      }
       float sm = 0.f;
-      for (int k = 0; k < K; ++k) sm += __expf(al[k][row] - m);
+#pragma unroll
+      for (int k = 0; k < FW * KQ; ++k) sm += __builtin_amdgcn_exp2f(1.44269504f * (av[k] - m));
       const float lse = m + __logf(sm);
       const bool valid = tile * FT + row < n;
       if (wave == 0 && valid) logp_acc += (double)(lse - row_level);
