@@ -20,7 +20,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 104     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 105     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -103,6 +103,9 @@ def lib():
                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_rwm_fused.argtypes = [i32, vp, vp, i64, i32, i32, bp, i32, i32, f32, i32, u64, u64, i32,
                                     vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_advi_meanfield_sample.argtypes = [i32, i32, vp, vp, vp, vp, vp]
+        l.bvi_advi_meanfield_grads.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_clip_adam_step.argtypes = [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp]
         l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]
         l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
         for name in ('bvi_constrain', 'bvi_posterior_assemble', 'bvi_leapfrog_pre', 'bvi_leapfrog_post',
@@ -112,7 +115,8 @@ def lib():
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
-                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase'):
+                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads',
+                     'bvi_clip_adam_step'):
             getattr(l, name).restype = i32
         _lib = l
     return _lib

@@ -2,6 +2,7 @@
 import numpy as np
 import torch
 
+from ... import _native
 from ...fused_target import differentiable_log_prob, replicate_from_rank0
 from ..inference import Inference
 
@@ -105,7 +106,48 @@ class VI(Inference):
         finite = torch.isfinite(d)
         return torch.where(finite, d, torch.zeros_like(d)).sum() / finite.sum()
 
+    # ---- mean-field ADVI with the built-in priors / bijectors: the whole step on the device without autograd ----
+    def _fused_advi_eligible(self, opt):
+        from .surrogate_posteriors import ADVI
+        sur = self.surrogate_posterior
+        return (getattr(self, 'fused_advi', True) and isinstance(sur, ADVI) and sur.mean_field
+                and sur.extra_ndims == 0 and self.discrepancy_fn is kl_reverse and isinstance(opt, _AdamState)
+                and self.device.type == 'cuda' and self.posterior.device_blocks() is not None
+                and sur.loc.requires_grad and sur.raw_scale.requires_grad
+                and [id(p) for p in opt.params] == [id(sur.loc), id(sur.raw_scale)])
+
+    def _step_fused_advi(self, opt, sample_size):
+        """One step of `_step` for the mean-field ADVI surrogate when the model's priors and bijectors are the
+        device-side ones: sample -> constrain -> fused data pass -> assemble -> closed-form ELBO gradients ->
+        per-variable clip + Adam, eight launches (surrogate_posteriors.py:113-123, vi.py:55-75, 109-116).  Same
+        loss, clipped gradients (left in `.grad`) and parameters as autograd over the same formulas."""
+        lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
+        sur, post = self.surrogate_posterior, self.posterior
+        s, pu = int(sample_size), sur.unconstrained_event_ndims
+        eps = sur.base_noise(s, pu).contiguous()
+        b = getattr(self, '_advi_bufs', None)
+        if b is None or b['z'].shape != (s, pu):
+            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
+            b = self._advi_bufs = dict(z=f(s, pu), loss=f(()))
+        for prm in (sur.loc, sur.raw_scale):
+            if prm.grad is None:
+                prm.grad = torch.zeros_like(prm)
+        with torch.no_grad():
+            _native.check(lib.bvi_advi_meanfield_sample(s, pu, ptr(eps), ptr(sur.loc), ptr(sur.raw_scale), ptr(b['z']), st),
+                          'bvi_advi_meanfield_sample')
+            lp, gz = post.unconstrained_log_prob_and_grad(b['z'], True)
+            _native.check(lib.bvi_advi_meanfield_grads(s, pu, ptr(lp), ptr(gz), ptr(eps), ptr(sur.raw_scale), ptr(b['loss']),
+                                                       ptr(sur.loc.grad), ptr(sur.raw_scale.grad), st),
+                          'bvi_advi_meanfield_grads')
+            for i, (prm, m, v) in enumerate(zip(opt.params, opt.m, opt.v)):
+                _native.check(lib.bvi_clip_adam_step(prm.numel(), ptr(prm), ptr(prm.grad), ptr(m), ptr(v), ptr(opt.t),
+                                                     1 if i == 0 else 0, opt.lr, opt.b1, opt.b2, opt.eps, 1.0, st),
+                              'bvi_clip_adam_step')
+        return b['loss'].clone()
+
     def _step(self, opt, params, sample_size):
+        if self._fused_advi_eligible(opt):
+            return self._step_fused_advi(opt, sample_size)
         opt.zero_grad(set_to_none=False)
         loss = self.loss(sample_size)
         loss.backward()

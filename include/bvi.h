@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 104
+#define BVI_VERSION 105
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -289,6 +289,27 @@ int bvi_nuts_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, vo
 int bvi_nuts_subtree_begin(const bvi_nuts_state* state, uint64_t seed, uint64_t step, int depth, void* stream);
 int bvi_nuts_leaf(const bvi_nuts_state* state, uint64_t seed, uint64_t step, int leaf, int* any_building, void* stream);
 int bvi_nuts_subtree_end(const bvi_nuts_state* state, int* any_active, void* stream);
+
+/* ---- one mean-field ADVI optimisation step around the fused log-posterior pass (what a GradientTape over
+ * tfp.vi.monte_carlo_variational_loss, tf.clip_by_norm per variable and tf.optimizers.Adam do in
+ * bayes_vi/inference/vi/vi.py:55-75, 109-116 for the surrogate of surrogate_posteriors.py:113-123):
+ *   bvi_advi_meanfield_sample   z[S,Pu] = loc + softplus(raw_scale) * eps[S,Pu]
+ *   (bvi_constrain, <family>_logp_grad, bvi_posterior_assemble: lp[S] = log pi(z_s), grad_z[S,Pu])
+ *   bvi_advi_meanfield_grads    loss = -mean_s (lp_s - log q(z_s)) over the samples where it is finite (vi.py:55-58),
+ *                               grad_loc[Pu], grad_raw_scale[Pu] = d loss / d (loc, raw_scale)
+ *   bvi_clip_adam_step          per variable: grad <- grad * clip_norm / max(|grad|, clip_norm) (in place; 0 = no
+ *                               clipping), then m, v, x updated with lr_t = lr sqrt(1 - b2^t) / (1 - b1^t),
+ *                               x -= lr_t m / (sqrt(v) + epsilon); *step_count (device double) is t - 1 on entry
+ *                               when advance_step != 0 (first variable of a step) and t otherwise.
+ * All arrays are device memory; nothing allocates or synchronises. */
+int bvi_advi_meanfield_sample(int n_samples, int n_unconstrained, const float* eps, const float* loc,
+                              const float* raw_scale, float* z, void* stream);
+int bvi_advi_meanfield_grads(int n_samples, int n_unconstrained, const float* lp, const float* grad_z,
+                             const float* eps, const float* raw_scale, float* loss, float* grad_loc,
+                             float* grad_raw_scale, void* stream);
+int bvi_clip_adam_step(int n, float* x, float* grad, float* m, float* v, double* step_count, int advance_step,
+                       float learning_rate, float beta_1, float beta_2, float epsilon, float clip_norm,
+                       void* stream);
 
 /* Whole HMC transitions in one launch, for datasets small enough that one workgroup per chain can
  * re-stream them at every leapfrog step (tens to ~10^5 rows): per transition a Philox momentum draw,

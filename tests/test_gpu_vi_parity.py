@@ -287,3 +287,51 @@ def test_non_finite_samples_are_dropped_on_the_device(bvi, gpu_device):
     assert_logp_close(np.array([float(loss.detach())]), np.array([ref_loss]))
     assert_grad_close(sur.loc.grad.cpu().numpy()[None], ref_grads['loc'][None])
     assert_grad_close(sur.raw_scale.grad.cpu().numpy()[None], ref_grads['raw_scale'][None])
+
+
+def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device):
+    """Mean-field ADVI on a model with the built-in priors / bijectors takes the step without autograd (sample,
+    data pass, closed-form ELBO gradients, clip + Adam in device kernels).  Same loss, clipped gradients, Adam
+    moments and variables as the autograd path, step by step -- also with a sample whose log density is not finite
+    (dropped from the mean, vi.py:55-58) -- and VI.fit replays it as a graph with the same result."""
+    d, s = 5, 16
+    model, ds, spec, _ = regression(bvi, gpu_device, 5_000, d, seed=81)
+    rng = np.random.default_rng(82)
+    noise = [f32_noise(rng, (s, spec.pu)) for _ in range(4)]
+    noise[2][3, -1] = -3000.0
+    runs = {}
+    for fused in (True, False):
+        torch.manual_seed(11)
+        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=True))
+        vi.fused_advi = fused
+        sur = vi.surrogate_posterior
+        inject(sur, noise, gpu_device)
+        params = [p for p in sur.parameters() if p.requires_grad]
+        opt = bvi.Adam(learning_rate=0.05).bind(params)
+        assert vi._fused_advi_eligible(opt) == fused
+        rec = []
+        for _ in range(4):
+            loss = vi._step(opt, params, s)
+            rec.append((float(loss), sur.loc.grad.clone(), sur.raw_scale.grad.clone(), sur.loc.detach().clone(),
+                        sur.raw_scale.detach().clone(), [m.clone() for m in opt.m], [v.clone() for v in opt.v]))
+        assert float(opt.t) == 4.0
+        runs[fused] = rec
+    for a, b in zip(runs[True], runs[False]):
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0])
+        for x, y in zip(a[1:5], b[1:5]):
+            assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()) + 1e-7
+        for xs, ys in zip(a[5:], b[5:]):
+            for x, y in zip(xs, ys):
+                assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()) + 1e-9
+    # through VI.fit: three eager steps, then graph replay of the fused step
+    fits = {}
+    for capture in (True, False):
+        torch.manual_seed(11)
+        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=True))
+        torch.manual_seed(12)
+        _, losses = vi.fit(optimizer=bvi.Adam(learning_rate=0.05), num_steps=12, sample_size=s,
+                           num_samples_to_approx_marginals=10, progress_bar=False, capture_graph=capture)
+        fits[capture] = (losses, vi.surrogate_posterior.loc.detach().clone())
+    assert np.isfinite(fits[True][0]).all() and fits[True][0][-1] < fits[True][0][0]
+    np.testing.assert_allclose(fits[True][0], fits[False][0], rtol=1e-5)
+    assert float((fits[True][1] - fits[False][1]).abs().max()) <= 1e-5
