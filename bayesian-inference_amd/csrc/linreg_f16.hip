@@ -415,7 +415,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int D, int NW>
+// GRAD = false (value only: what random-walk Metropolis asks for).  S2's compensation still needs G_k = sum xh r_k,
+// but only through the product dw . G_k with dw ~ 2^-13 of the weights, for which the high f16 piece of the
+// residuals is plenty: the low piece, its share of the split and its gradient products are left out (a third of
+// the matrix instructions and two of seven vector instructions per residual pair).
+template <int D, int NW, bool GRAD>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void linreg_f16_pipe_kernel(
     const unsigned char* __restrict__ packed, int64_t n, int dr, const float* __restrict__ theta, int C, int ncb,
     int nrb, float* __restrict__ partials) {
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 : __builtin_bit_cast(f16x8, (u32x4){RL[sr][ct][0], RL[sr][ct][1], RL[sr][ct][2], RL[sr][ct][3]});
             const f16x8 xv = __builtin_bit_cast(
                 f16x8, __builtin_shufflevector(XH[sr][ft][0], XH[sr][ft][1], 0, 1, 2, 3, 4, 5, 6, 7));
-            G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rv, xv, G[ct][ft], 0, 0, 0);
+            if constexpr (GRAD || piece == 0) G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rv, xv, G[ct][ft], 0, 0, 0);
           }
           // -- the slot's share of Q(j): job = (chain tile ct, residual pair jp) -> element pair of Z[sq]
           static_for<JPG>([&](auto jb_) {
@@ -651,15 +655,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
               const unsigned hi = RH[sq][ct][jp];
               unsigned lo;
               a2[ct] = fmaf(q0, q0, a2[ct]);
-              asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(q0), "v"(hi));
-              RL[sq][ct][jp] = lo;
+              if constexpr (GRAD) {
+                asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(q0), "v"(hi));
+                RL[sq][ct][jp] = lo;
+              }
             } else {
               const float q1 = Z[sq][rt][ct][i0 + 1];
               const unsigned hi = RH[sq][ct][jp];
               unsigned lo = RL[sq][ct][jp];
               a2[ct] = fmaf(q1, q1, a2[ct]);
-              asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(q1), "v"(hi));
-              RL[sq][ct][jp] = lo;
+              if constexpr (GRAD) {
+                asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(q1), "v"(hi));
+                RL[sq][ct][jp] = lo;
+              }
             }
           });
           __builtin_amdgcn_sched_barrier(0);
@@ -680,7 +688,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const f16x8 rl = __builtin_bit_cast(f16x8, (u32x4){RL[1][ct][0], RL[1][ct][1], RL[1][ct][2], RL[1][ct][3]});
         const f16x8 xv = __builtin_bit_cast(f16x8, __builtin_shufflevector(XH[1][ft][0], XH[1][ft][1], 0, 1, 2, 3, 4, 5, 6, 7));
         G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh, xv, G[ct][ft], 0, 0, 0);
-        G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl, xv, G[ct][ft], 0, 0, 0);
+        if constexpr (GRAD) G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl, xv, G[ct][ft], 0, 0, 0);
       }
   }
 
@@ -1166,17 +1174,24 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return BVI_ERR_ARG;
   if (!lds_ok[dev]) {
-    hipError_t e = pipelined ? hipFuncSetAttribute((const void*)&linreg_f16_pipe_kernel<D, NW>,
+    hipError_t e = pipelined ? hipFuncSetAttribute((const void*)&linreg_f16_pipe_kernel<D, NW, true>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                              : hipFuncSetAttribute((const void*)&linreg_f16_kernel<D, NW, CT>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && pipelined)
+      e = hipFuncSetAttribute((const void*)&linreg_f16_pipe_kernel<D, NW, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     lds_ok[dev] = true;
   }
-  if constexpr (pipelined)
-    hipLaunchKernelGGL((linreg_f16_pipe_kernel<D, NW>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb,
-                       nrb, ws);
-  else
+  if constexpr (pipelined) {
+    if (grad)
+      hipLaunchKernelGGL((linreg_f16_pipe_kernel<D, NW, true>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta,
+                         c, ncb, nrb, ws);
+    else
+      hipLaunchKernelGGL((linreg_f16_pipe_kernel<D, NW, false>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d,
+                         theta, c, ncb, nrb, ws);
+  } else
     hipLaunchKernelGGL((linreg_f16_kernel<D, NW, CT>), dim3(ncb * nrb), dim3(64 * NW), lds, s, pk, n, d, theta, c, ncb,
                        nrb, ws);
   BVI_HIP_CHECK_LAUNCH();

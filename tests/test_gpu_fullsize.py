@@ -87,6 +87,12 @@ def test_regression_10m_rows_1024_chains_against_float64_statistics(nat, ws, reg
     # determinism at full size
     lp2, g2 = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
     assert torch.equal(lp, lp2) and torch.equal(g, g2)
+    # value only (random-walk Metropolis): the many-chain kernel leaves out the residuals' low f16 piece, which the
+    # log density needs only through a 2^-13-sized compensation term -- same values to float rounding
+    lpv, none = nat.linreg_packed_logp_grad(pk, n, d, th, ws, want_grad=False, fmt=nat.PACK_F16)
+    assert none is None
+    _close(lpv, ref_lp, ref_lp.abs(), what='logp f16 pieces, value only')
+    assert float((lpv.double() - lp.double()).abs().max()) <= 4.0      # two float steps at 1e7..1e9
     r['full'] = (lp, g)
 
 
@@ -136,13 +142,20 @@ def test_log_density_differences_at_10m_rows(nat, ws, regression_10m):
     lp_abs, _ = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
     err_abs = lp_abs.double() - ref64
     level = _level_of(nat, lp_abs)
-    for cc in (64, 16):                                            # two-tile-per-wave and one-tile-per-wave kernels
+    th = torch.cat([th, th[:64] + 0.0, th[:64] + 0.0], 0)[:128].contiguous()   # 128 chains: the two-tiles-per-wave kernel
+    ref64 = torch.cat([ref64, ref64], 0)[:128]
+    for cc in (128, 64, 16):                                       # many-chain (pipelined) and one-tile-per-wave kernels
         lp, _ = nat.linreg_packed_logp_grad(pk, n, d, th[:cc].contiguous(), ws, fmt=nat.PACK_F16, logp_ref=level)
         err = lp.double() + level - ref64[:cc]
         assert float((err - err.mean()).abs().max()) <= 1e-2, float((err - err.mean()).abs().max())
         lpv, _ = nat.linreg_packed_logp_grad(pk, n, d, th[:cc].contiguous(), ws, want_grad=False, fmt=nat.PACK_F16,
                                              logp_ref=level)
-        assert torch.equal(lp, lpv)
+        if cc <= 64:
+            assert torch.equal(lp, lpv)
+        else:                 # value-only form of the many-chain kernel: the residuals' high f16 piece only
+            errv = lpv.double() + level - ref64[:cc]
+            assert float((errv - errv.mean()).abs().max()) <= 1e-2, float((errv - errv.mean()).abs().max())
+    th, ref64 = th[:64].contiguous(), ref64[:64]
     # the absolute float outputs cannot do that (documented, not required): their spread is the float spacing
     assert float((err_abs - err_abs.mean()).abs().max()) > 0.1
     # two row shards, each relative to its own level (half of the total, as bvi_logp_rebase leaves them): they add

@@ -14,6 +14,7 @@ ap.add_argument('--prec', default='bf16x6')
 ap.add_argument('--check', action='store_true')
 ap.add_argument('--packed', action='store_true')
 ap.add_argument('--f16', action='store_true')
+ap.add_argument('--value-only', action='store_true', help='no gradient (what random-walk Metropolis calls)')
 ap.add_argument('--lib', default=None, help='alternative build of the library (kernel experiments)')
 a = ap.parse_args()
 if a.lib:
@@ -31,7 +32,8 @@ th = torch.cat([0.5 + 0.01 * torch.randn(a.chains, 1, generator=g, device=dev),
 prec = {'auto': 0, 'f32': 1, 'bf16x3': 2, 'bf16x6': 3}[a.prec]
 if a.f16:
     pk = nat.linreg_pack(X, y, fmt=nat.PACK_F16)
-    run = lambda: nat.linreg_packed_logp_grad(pk, a.rows, a.d, th, ws, precision=0, fmt=nat.PACK_F16)
+    run = lambda: nat.linreg_packed_logp_grad(pk, a.rows, a.d, th, ws, precision=0, fmt=nat.PACK_F16,
+                                              want_grad=not a.value_only)
 elif a.packed:
     pk = nat.linreg_pack(X, y)
     run = lambda: nat.linreg_packed_logp_grad(pk, a.rows, a.d, th, ws, precision=prec)
