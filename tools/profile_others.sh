@@ -10,7 +10,7 @@ run() {   # name, program...
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -o t -- python3 "$@" > "$OUT/$name.log" 2>&1
   local f; f=$(find "$OUT/$name" -name '*_kernel_stats.csv' | head -1)
   head -12 "$f" > "$OUT/${TAG}_${name}_kernel_stats.csv"
-  grep -E "steps in|chains x|ELBO|rows=|fullcov N" "$OUT/$name.log" | head -12 > "$OUT/${TAG}_${name}_output.txt" || true
+  grep -E "steps in|chains x|ELBO|rows=|fullcov N|ms/transition" "$OUT/$name.log" | head -12 > "$OUT/${TAG}_${name}_output.txt" || true
   rm -rf "$OUT/$name"
   echo "== $name"; cut -c1-150 "$OUT/${TAG}_${name}_kernel_stats.csv" | head -6
 }
