@@ -365,8 +365,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // LDS: two f16 images of the tile (hi, lo), 64-B rows with the 16-B chunks XOR-swizzled by row so that the
   // A-operand ds_read_b128 (16 rows x two neighbouring chunks per lane group) is conflict-free; double buffered
   __shared__ __attribute__((aligned(16))) unsigned char ybuf[2][2][FT * 64];
-  __shared__ float al[FW * KQ][FT];     // a_ik of the tile
-  __shared__ float sq[FW * KQ][FT];     // sqrt(rho_ik) of the tile (0 for rows past the end)
+  __shared__ float al[FW * KQ][FT + 4];   // a_ik of the tile (rows padded: the per-row pass reads a column of it)
+  __shared__ float sq[FW * KQ][FT + 4];   // sqrt(rho_ik) of the tile (0 for rows past the end)
   __shared__ float cks[FW * KQ];        // the components' constants
   __shared__ float lpw[FT];
 
@@ -541,37 +541,34 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     __syncthreads();
     {
-      // log-sum-exp of the row (every wave for all 64 rows: the redundancy is cheaper than a second barrier), then
-      // sqrt(rho_ik) = exp((a_ik - lse) / 2) for this wave's components, once per (row, component) instead of once
-      // per lane that needs it
-      const int row = lane;
-      // all FW KQ loads in flight at once (a loop over the run-time K waits for one LDS round trip per component:
-      // 2 x 16 of them were half of the tile's time)
-      float av[FW * KQ];
-#pragma unroll
-      for (int k = 0; k < FW * KQ; ++k) av[k] = al[k][row];
-      float m = -INFINITY;
-#pragma unroll
-      for (int k = 0; k < FW * KQ; ++k) {
-        av[k] = k < K ? av[k] : -INFINITY;
-        m = fmaxf(m, av[k]);
-      }
-      float sm = 0.f;
-#pragma unroll
-      for (int k = 0; k < FW * KQ; ++k) sm += __builtin_amdgcn_exp2f(1.44269504f * (av[k] - m));
+      // log-sum-exp over the components and sqrt(rho_ik) = exp((a_ik - lse) / 2), shared out over the workgroup: wave w
+      // takes rows 8 w .. 8 w + 7, lane = (row, component pair kp and kp + 8); maxima and sums cross the eight
+      // component lanes of a row with three lane exchanges.  Every (row, component) is exponentiated once per
+      // tile -- when every wave did all 64 rows for itself, the K exponentials per lane were a seventh of the
+      // kernel's vector work.
+      const int rl = lane & 7, kp = lane >> 3, row = 8 * wave + rl;
+      const bool v0 = kp < K, v1 = KQ == 2 && kp + FW < K;
+      const float a0 = v0 ? al[kp][row] : -INFINITY;
+      const float a1 = v1 ? al[KQ == 2 ? kp + FW : kp][row] : -INFINITY;
+      float m = fmaxf(a0, a1);
+      m = fmaxf(m, __shfl_xor(m, 8, 64));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sm = __builtin_amdgcn_exp2f(1.44269504f * (a0 - m)) + __builtin_amdgcn_exp2f(1.44269504f * (a1 - m));
+      sm += __shfl_xor(sm, 8, 64);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
       const float lse = m + __logf(sm);
       const bool valid = tile * FT + row < n;
-      if (wave == 0 && valid) logp_acc += (double)(lse - row_level);
-      const float lsev = valid ? lse : INFINITY;
-#pragma unroll
-      for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
-        const int k = wave + FW * q;
-        if (k < K) {
-          // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
-          // the gradient sums instead of turning them into NaN; its log-density is already counted
-          const float aik = al[k][row];
-          sq[k][row] = (aik > cks[k] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (aik - lsev));
-        }
+      if (kp == 0 && valid) logp_acc += (double)(lse - row_level);
+      if (GRAD) {
+        // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
+        // the gradient sums instead of turning them into NaN; its log-density is already counted
+        const float lsev = valid ? lse : INFINITY;
+        if (v0) sq[kp][row] = (a0 > cks[kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a0 - lsev));
+        if (v1)
+          sq[KQ == 2 ? kp + FW : kp][row] =
+              (a1 > cks[KQ == 2 ? kp + FW : kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a1 - lsev));
       }
     }
     if (GRAD) __syncthreads();
@@ -648,7 +645,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
   }
-  if (tid < FT) lpw[tid] = (float)logp_acc;
+  if ((lane >> 3) == 0) lpw[8 * wave + (lane & 7)] = (float)logp_acc;   // the lanes that summed rows 8 w + (0..7)
   __syncthreads();
   if (tid == 0) {
     float s = 0.f;

@@ -4,6 +4,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
 from bayes_vi_amd import _native as nat
+if '--lib' in sys.argv:
+    nat._LIB_PATH = os.path.abspath(sys.argv[sys.argv.index('--lib') + 1])
 n, d, k, c = 1_000_000, 32, 16, 64
 dev = torch.device('cuda:0'); ws = nat.Workspace(dev)
 g = torch.Generator(device=dev); g.manual_seed(5)
