@@ -1,7 +1,7 @@
 """Per-column gradient error of the f16-piece kernel and the exact-f32 kernel on badly scaled columns."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
 from bayes_vi_amd import _native as nat
 from oracle import closed_form as cf

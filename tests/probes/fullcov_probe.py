@@ -2,7 +2,7 @@
 for data centred at the origin and far from it.  Run once as is (f16 pieces) and once with BVI_FULLCOV_F32=1."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
 from bayes_vi_amd import _native as nat
 from oracle import closed_form as cf
