@@ -230,12 +230,16 @@ def main():
     _native.check(lib.bvi_posterior_assemble(blocks, nb, c, ptr(z), ptr(theta), ptr(logp), ptr(grad), ptr(lp),
                                              ptr(g), st), 'bvi_posterior_assemble')
 
+    # One trajectory of warmup + steps leapfrog steps, as the device sampler runs it: the first half step once
+    # (bvi_leapfrog_pre), then per step the fused data pass [+ all-reduce] and bvi_leapfrog_mid -- the second half of
+    # this step (priors, Jacobian terms, chain rule, p += eps/2 g) and the first half of the next (z += eps p,
+    # theta = f(z)) in one launch.  Every step evaluates the gradient once and advances position and momentum once.
+    _native.check(lib.bvi_leapfrog_pre(blocks, nb, c, eps, ptr(z), ptr(p), ptr(g), ptr(theta), st), 'pre')
+
     def leapfrog_step(timed):
-        st = _native._stream()
-        _native.check(lib.bvi_leapfrog_pre(blocks, nb, c, eps, ptr(z), ptr(p), ptr(g), ptr(theta), st), 'pre')
         likelihood_pass(timed)
-        _native.check(lib.bvi_leapfrog_post(blocks, nb, c, eps, ptr(z), ptr(p), ptr(theta), ptr(logp), ptr(grad),
-                                            ptr(lp), ptr(g), st), 'post')
+        _native.check(lib.bvi_leapfrog_mid(blocks, nb, c, eps, ptr(z), ptr(p), ptr(theta), ptr(logp), ptr(grad),
+                                           ptr(lp), ptr(g), _native._stream()), 'mid')
 
     for _ in range(args.warmup):
         leapfrog_step(False)
