@@ -223,7 +223,7 @@ __device__ __forceinline__ void mix_store_partials(const float (*red)[256], int 
 #define BVI_GMM_WAVES 6
 #endif
 template <int K, int CP, bool GRAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? BVI_GMM_WAVES : 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? (CP == 64 ? BVI_GMM_WAVES : 4) : 3)))   // fewer chains per wave: no spills at 4
 void gmm1d_kernel(const float* __restrict__ y, int64_t n, int kreal,
                                                     const float* __restrict__ theta, int C, int nbins,
                                                     float* __restrict__ partials) {
