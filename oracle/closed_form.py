@@ -1,9 +1,15 @@
 """fp64 numpy closed forms of the bayes_vi log-posterior hot path (TEST ORACLE).
 
 Test infrastructure only -- see ``oracle/__init__.py``.  Parity against the
-TFP outputs of the reference is unpinned (TFP cannot run here); these closed
-forms are pinned against scipy.stats / torch.distributions / finite
-differences in tests/test_oracle_pins.py.
+TFP outputs of the reference is unpinned (TFP cannot run here).  What pins these
+closed forms instead (tests/test_oracle_pins.py, tests/test_host_logic.py):
+  normal_iid, linreg : the reference's own result tables -- the NUTS posterior mean / sd of
+                       univariate_gaussian_experiment/tables/... and of the 8 datasets of
+                       linear_regression_experiment/tables/..., reproduced to their printed decimals by
+                       quadrature of these posteriors -- plus scipy.stats / torch.distributions and
+                       finite differences;
+  gmm1d, gmm_fullcov : scipy.stats / torch.distributions and finite differences only -- the reference
+                       holds no table or fixture for the mixtures: PARITY UNPINNED for these two.
 
 What the reference computes on this path
 ----------------------------------------
