@@ -447,6 +447,9 @@ def test_gmm1d(nat, ws, gpu_device, k, c, n):
     ts = np.concatenate([n / th[:, :k], n / th[:, 2 * k:] * np.ones((c, k)), 3 * n / th[:, 2 * k:]], -1) * 0.3
     assert_logp_close(lp.cpu().numpy(), ref_lp)
     assert_grad_close(g.cpu().numpy(), ref_g, term_scale=ts)
+    # the value-only instantiations (what random-walk Metropolis calls) return the same log-densities
+    lpv, none = nat.gmm1d_logp_grad(dev(y, gpu_device), dev(th, gpu_device), k, ws, want_grad=False)
+    assert none is None and torch.equal(lp, lpv)
 
 
 @pytest.mark.parametrize('d,k,c,n', [(2, 4, 3, 100), (4, 3, 2, 25), (8, 5, 4, 1000), (32, 16, 2, 500), (32, 16, 5, 4099),
