@@ -20,7 +20,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 105     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 106     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -105,6 +105,8 @@ def lib():
                                     vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_advi_meanfield_sample.argtypes = [i32, i32, vp, vp, vp, vp, vp]
         l.bvi_advi_meanfield_grads.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        l.bvi_advi_fullrank_sample.argtypes = [i32, i32, vp, vp, vp, vp, vp]
+        l.bvi_advi_fullrank_grads.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_clip_adam_step.argtypes = [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp]
         l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]
         l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
@@ -115,7 +117,8 @@ def lib():
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
-                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads',
+                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads', 'bvi_advi_fullrank_sample',
+                     'bvi_advi_fullrank_grads',
                      'bvi_clip_adam_step'):
             getattr(l, name).restype = i32
         _lib = l

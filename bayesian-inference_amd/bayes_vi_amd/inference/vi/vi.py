@@ -126,18 +126,20 @@ class VI(Inference):
         finite = torch.isfinite(d)
         return torch.where(finite, d, torch.zeros_like(d)).sum() / finite.sum()
 
-    # ---- mean-field ADVI with the built-in priors / bijectors: the whole step on the device without autograd ----
+    # ---- ADVI (mean-field or full-rank) with the built-in priors / bijectors: the whole step on the device, no autograd ----
     def _fused_advi_eligible(self, opt):
         from .surrogate_posteriors import ADVI
         sur = self.surrogate_posterior
-        return (getattr(self, 'fused_advi', True) and isinstance(sur, ADVI) and sur.mean_field
-                and sur.extra_ndims == 0 and self.discrepancy_fn is kl_reverse and isinstance(opt, _AdamState)
-                and self.device.type == 'cuda' and self.posterior.device_blocks() is not None
-                and sur.loc.requires_grad and sur.raw_scale.requires_grad
-                and [id(p) for p in opt.params] == [id(sur.loc), id(sur.raw_scale)])
+        if not (getattr(self, 'fused_advi', True) and isinstance(sur, ADVI) and sur.extra_ndims == 0
+                and self.discrepancy_fn is kl_reverse and isinstance(opt, _AdamState) and self.device.type == 'cuda'
+                and self.posterior.device_blocks() is not None):
+            return False
+        scale = sur.raw_scale if sur.mean_field else sur.raw_tril
+        return (sur.loc.requires_grad and scale.requires_grad and scale.is_contiguous()
+                and [id(p) for p in opt.params] == [id(sur.loc), id(scale)])
 
     def _step_fused_advi(self, opt, sample_size):
-        """One step of `_step` for the mean-field ADVI surrogate when the model's priors and bijectors are the
+        """One step of `_step` for the ADVI surrogates (mean-field, full-rank) when the model's priors and bijectors are the
         device-side ones: sample -> constrain -> fused data pass -> assemble -> closed-form ELBO gradients ->
         per-variable clip + Adam, eight launches (surrogate_posteriors.py:113-123, vi.py:55-75, 109-116).  Same
         loss, clipped gradients (left in `.grad`) and parameters as autograd over the same formulas."""
@@ -149,16 +151,17 @@ class VI(Inference):
         if b is None or b['z'].shape != (s, pu):
             f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
             b = self._advi_bufs = dict(z=f(s, pu), loss=f(()))
-        for prm in (sur.loc, sur.raw_scale):
+        scale = sur.raw_scale if sur.mean_field else sur.raw_tril
+        sample, grads = ((lib.bvi_advi_meanfield_sample, lib.bvi_advi_meanfield_grads) if sur.mean_field
+                         else (lib.bvi_advi_fullrank_sample, lib.bvi_advi_fullrank_grads))
+        for prm in (sur.loc, scale):
             if prm.grad is None:
                 prm.grad = torch.zeros_like(prm)
         with torch.no_grad():
-            _native.check(lib.bvi_advi_meanfield_sample(s, pu, ptr(eps), ptr(sur.loc), ptr(sur.raw_scale), ptr(b['z']), st),
-                          'bvi_advi_meanfield_sample')
+            _native.check(sample(s, pu, ptr(eps), ptr(sur.loc), ptr(scale), ptr(b['z']), st), 'bvi_advi_*_sample')
             lp, gz = post.unconstrained_log_prob_and_grad(b['z'], True)
-            _native.check(lib.bvi_advi_meanfield_grads(s, pu, ptr(lp), ptr(gz), ptr(eps), ptr(sur.raw_scale), ptr(b['loss']),
-                                                       ptr(sur.loc.grad), ptr(sur.raw_scale.grad), st),
-                          'bvi_advi_meanfield_grads')
+            _native.check(grads(s, pu, ptr(lp), ptr(gz), ptr(eps), ptr(scale), ptr(b['loss']), ptr(sur.loc.grad),
+                                ptr(scale.grad), st), 'bvi_advi_*_grads')
             for i, (prm, m, v) in enumerate(zip(opt.params, opt.m, opt.v)):
                 _native.check(lib.bvi_clip_adam_step(prm.numel(), ptr(prm), ptr(prm.grad), ptr(m), ptr(v), ptr(opt.t),
                                                      1 if i == 0 else 0, opt.lr, opt.b1, opt.b2, opt.eps, 1.0, st),

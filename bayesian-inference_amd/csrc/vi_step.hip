@@ -78,6 +78,84 @@ __global__ __launch_bounds__(256) void advi_grads_kernel(int S, int Pu, const fl
   }
 }
 
+// ---- full-rank ADVI: z_s = loc + L eps_s, L = tril(raw, -1) + diag(softplus(raw_dd) + 1e-5) (surrogate_posteriors.py:
+// 125-134); log q(z_s) = sum_j (-eps_sj^2 / 2 - log(2 pi) / 2) - sum_i log L_ii ----
+__device__ __forceinline__ float vi_tril_entry(const float* __restrict__ raw, int Pu, int i, int j) {
+  return i == j ? vi_softplus(raw[(int64_t)i * Pu + i]) + 1e-5f : raw[(int64_t)i * Pu + j];
+}
+
+__global__ void advi_fullrank_sample_kernel(int S, int Pu, const float* __restrict__ eps, const float* __restrict__ loc,
+                                            const float* __restrict__ raw, float* __restrict__ z) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)S * Pu) return;
+  const int i = (int)(idx % Pu);
+  const float* e = eps + (idx / Pu) * Pu;
+  float acc = loc[i];
+  for (int j = 0; j <= i; ++j) acc = fmaf(vi_tril_entry(raw, Pu, i, j), e[j], acc);
+  z[idx] = acc;
+}
+
+// block i < Pu: row i of d loss / d raw_tril and entry i of d loss / d loc; block Pu: the loss.
+//   d loss / d L_ij = -mean_s g_si eps_sj (j <= i) - [i == j] / L_ii;  the diagonal passes through softplus
+__global__ __launch_bounds__(256) void advi_fullrank_grads_kernel(int S, int Pu, const float* __restrict__ lp,
+                                                                  const float* __restrict__ gz,
+                                                                  const float* __restrict__ eps,
+                                                                  const float* __restrict__ raw,
+                                                                  float* __restrict__ loss,
+                                                                  float* __restrict__ g_loc,
+                                                                  float* __restrict__ g_raw) {
+  __shared__ double red[4];
+  __shared__ double part[4][64];
+  const int i = blockIdx.x;
+  if (i < Pu) {
+    double nf = 0.0, a = 0.0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+      const bool fin = isfinite(lp[s]);
+      nf += fin ? 1.0 : 0.0;
+      a += fin ? (double)gz[(int64_t)s * Pu + i] : 0.0;
+    }
+    nf = block_sum(nf, red); a = block_sum(a, red);
+    if (threadIdx.x == 0) g_loc[i] = (float)(-a / nf);
+    const int jl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    for (int j0 = 0; j0 < Pu; j0 += 64) {
+      const int j = j0 + jl;
+      double acc = 0.0;
+      if (j <= i)
+        for (int s = slice; s < S; s += 4)
+          if (isfinite(lp[s])) acc += (double)gz[(int64_t)s * Pu + i] * (double)eps[(int64_t)s * Pu + j];
+      __syncthreads();
+      part[slice][jl] = acc;
+      __syncthreads();
+      if (slice == 0 && j < Pu) {
+        double g = 0.0;
+        if (j <= i) {
+          g = -(part[0][jl] + part[1][jl] + part[2][jl] + part[3][jl]) / nf;
+          if (j == i) {
+            const float r = raw[(int64_t)i * Pu + i];
+            g = (g - 1.0 / ((double)vi_softplus(r) + 1e-5)) * (double)vi_sigmoid(r);
+          }
+        }
+        g_raw[(int64_t)i * Pu + j] = (float)g;      // above the diagonal: 0, as autograd through tril() leaves it
+      }
+    }
+  } else {
+    double lsig = 0.0;
+    for (int k = 0; k < Pu; ++k) lsig += log((double)vi_softplus(raw[(int64_t)k * Pu + k]) + 1e-5);
+    double nf = 0.0, a = 0.0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+      double e2 = 0.0;
+      for (int k = 0; k < Pu; ++k) { const double e = (double)eps[(int64_t)s * Pu + k]; e2 += e * e; }
+      const double logq = -0.5 * e2 - 0.5 * Pu * BVI_LN2PI_D - lsig;
+      const double d = -((double)lp[s] - logq);
+      const bool fin = isfinite(d);
+      nf += fin ? 1.0 : 0.0;
+      a += fin ? d : 0.0;
+    }
+    nf = block_sum(nf, red); a = block_sum(a, red);
+    if (threadIdx.x == 0) *loss = (float)(a / nf);
+  }
+}
+
 // one workgroup per variable: clip by norm, then the Keras-formulation Adam update
 //   m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2;  lr_t = lr sqrt(1 - b2^t) / (1 - b1^t);  x -= lr_t m / (sqrt(v) + eps)
 __global__ __launch_bounds__(256) void clip_adam_kernel(int n, float* __restrict__ x, float* __restrict__ g,
@@ -126,6 +204,28 @@ int bvi_advi_meanfield_grads(int n_samples, int n_unconstrained, const float* lp
     return BVI_ERR_ARG;
   hipLaunchKernelGGL(advi_grads_kernel, dim3(n_unconstrained + 1), dim3(256), 0, (hipStream_t)stream, n_samples,
                      n_unconstrained, lp, grad_z, eps, raw_scale, loss, grad_loc, grad_raw_scale);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
+int bvi_advi_fullrank_sample(int n_samples, int n_unconstrained, const float* eps, const float* loc,
+                             const float* raw_tril, float* z, void* stream) {
+  if (!eps || !loc || !raw_tril || !z || n_samples < 1 || n_unconstrained < 1) return BVI_ERR_ARG;
+  const int64_t tot = (int64_t)n_samples * n_unconstrained;
+  hipLaunchKernelGGL(advi_fullrank_sample_kernel, dim3((unsigned)bvi_ceil_div(tot, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_samples, n_unconstrained, eps, loc, raw_tril, z);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
+int bvi_advi_fullrank_grads(int n_samples, int n_unconstrained, const float* lp, const float* grad_z,
+                            const float* eps, const float* raw_tril, float* loss, float* grad_loc,
+                            float* grad_raw_tril, void* stream) {
+  if (!lp || !grad_z || !eps || !raw_tril || !loss || !grad_loc || !grad_raw_tril || n_samples < 1 ||
+      n_unconstrained < 1)
+    return BVI_ERR_ARG;
+  hipLaunchKernelGGL(advi_fullrank_grads_kernel, dim3(n_unconstrained + 1), dim3(256), 0, (hipStream_t)stream,
+                     n_samples, n_unconstrained, lp, grad_z, eps, raw_tril, loss, grad_loc, grad_raw_tril);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 105
+#define BVI_VERSION 106
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -307,6 +307,13 @@ int bvi_advi_meanfield_sample(int n_samples, int n_unconstrained, const float* e
 int bvi_advi_meanfield_grads(int n_samples, int n_unconstrained, const float* lp, const float* grad_z,
                              const float* eps, const float* raw_scale, float* loss, float* grad_loc,
                              float* grad_raw_scale, void* stream);
+/* The full-rank surrogate (scale_tril = tril(raw_tril, -1) + diag(softplus(diag raw_tril) + 1e-5),
+ * surrogate_posteriors.py:125-134) in the same two roles; grad_raw_tril[Pu,Pu] is zero above the diagonal. */
+int bvi_advi_fullrank_sample(int n_samples, int n_unconstrained, const float* eps, const float* loc,
+                             const float* raw_tril, float* z, void* stream);
+int bvi_advi_fullrank_grads(int n_samples, int n_unconstrained, const float* lp, const float* grad_z,
+                            const float* eps, const float* raw_tril, float* loss, float* grad_loc,
+                            float* grad_raw_tril, void* stream);
 int bvi_clip_adam_step(int n, float* x, float* grad, float* m, float* v, double* step_count, int advance_step,
                        float learning_rate, float beta_1, float beta_2, float epsilon, float clip_norm,
                        void* stream);

@@ -289,8 +289,9 @@ def test_non_finite_samples_are_dropped_on_the_device(bvi, gpu_device):
     assert_grad_close(sur.raw_scale.grad.cpu().numpy()[None], ref_grads['raw_scale'][None])
 
 
-def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device):
-    """Mean-field ADVI on a model with the built-in priors / bijectors takes the step without autograd (sample,
+@pytest.mark.parametrize('mean_field', [True, False])
+def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device, mean_field):
+    """Mean-field and full-rank ADVI on a model with the built-in priors / bijectors take the step without autograd (sample,
     data pass, closed-form ELBO gradients, clip + Adam in device kernels).  Same loss, clipped gradients, Adam
     moments and variables as the autograd path, step by step -- also with a sample whose log density is not finite
     (dropped from the mean, vi.py:55-58) -- and VI.fit replays it as a graph with the same result."""
@@ -302,9 +303,10 @@ def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device):
     runs = {}
     for fused in (True, False):
         torch.manual_seed(11)
-        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=True))
+        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=mean_field))
         vi.fused_advi = fused
         sur = vi.surrogate_posterior
+        scale = sur.raw_scale if mean_field else sur.raw_tril
         inject(sur, noise, gpu_device)
         params = [p for p in sur.parameters() if p.requires_grad]
         opt = bvi.Adam(learning_rate=0.05).bind(params)
@@ -312,8 +314,8 @@ def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device):
         rec = []
         for _ in range(4):
             loss = vi._step(opt, params, s)
-            rec.append((float(loss), sur.loc.grad.clone(), sur.raw_scale.grad.clone(), sur.loc.detach().clone(),
-                        sur.raw_scale.detach().clone(), [m.clone() for m in opt.m], [v.clone() for v in opt.v]))
+            rec.append((float(loss), sur.loc.grad.clone(), scale.grad.clone(), sur.loc.detach().clone(),
+                        scale.detach().clone(), [m.clone() for m in opt.m], [v.clone() for v in opt.v]))
         assert float(opt.t) == 4.0
         runs[fused] = rec
     for a, b in zip(runs[True], runs[False]):
@@ -327,7 +329,7 @@ def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device):
     fits = {}
     for capture in (True, False):
         torch.manual_seed(11)
-        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=True))
+        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=mean_field))
         torch.manual_seed(12)
         _, losses = vi.fit(optimizer=bvi.Adam(learning_rate=0.05), num_steps=12, sample_size=s,
                            num_samples_to_approx_marginals=10, progress_bar=False, capture_graph=capture)
