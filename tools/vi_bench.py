@@ -1,4 +1,4 @@
-"""BASELINE.json configs[4] on one GPU: ELBO gradient steps of mean-field ADVI (and a Hamiltonian-flow surrogate)
+"""BASELINE.json configs[4] on one GPU: ELBO gradient steps of mean-field and full-rank ADVI (and a Hamiltonian-flow surrogate)
 on the 10M x 64 regression with 256 Monte-Carlo samples per step."""
 import collections, os, sys, time
 import numpy as np, pandas as pd, torch
@@ -25,6 +25,7 @@ priors = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros
 model = Model(priors, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
 ds = TensorDataset(X, y)
 for name, make in (('mean-field ADVI', lambda: ADVI(model, mean_field=True)),
+                   ('full-rank ADVI', lambda: ADVI(model, mean_field=False)),
                    ('Hamiltonian flow (2 layers)', None)):
     if make is None:
         try:
