@@ -280,6 +280,45 @@ __device__ __forceinline__ float row16_sum_step(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true));
 }
 
+// Sums of four values over the 16 lanes of a DPP row in 8 instead of 16 lane-crossing adds: the first two steps fold
+// across the row's four banks of four lanes and halve the number of values each time (bank masks pick which value a
+// bank keeps), the last two run inside a bank.  After step 3 every lane of bank b holds the sum of v[b].  One call
+// per step so that the caller can put other work between them; the s_nop covers the two wait states a lane-crossing
+// read needs after the write of its source, which the assembler does not insert inside an asm statement.
+struct Row16Sum4 {
+  float d0, d1;
+  __device__ __forceinline__ void step0(const float (&v)[4]) {   // lanes L and 15 - L: banks 0, 1 keep v0, v1; 2, 3 keep v2, v3
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xc"
+        : "=&v"(d0), "=&v"(d1)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  }
+  __device__ __forceinline__ void step1() {                      // lanes L and 7 - L of a half row: bank b keeps v[b]
+    float e;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa"
+        : "=&v"(e)
+        : "v"(d0), "v"(d1));
+    d0 = e;
+  }
+  __device__ __forceinline__ void step2() {
+    float e;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(e) : "v"(d0));
+    d0 = e;
+  }
+  __device__ __forceinline__ void step3() {
+    float e;
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(e) : "v"(d0));
+    d0 = e;
+  }
+};
+
 // sum over the 16 lanes of a DPP row, result in every lane
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -421,10 +460,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   if (tid < FW * KQ) cks[tid] = tid < K ? cst[c * K + tid] : -INFINITY;   // visible after the barrier below
 
   f32x4 S2[KQ][2][2];
-  float S1[KQ][2], S0[KQ];
+  float S1[KQ][2];
+  float S0a = 0.f, S0b = 0.f;                 // sum of rho for components lane >> 3 (and + FW) over rows 8 wave + (lane & 7)
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
-    S0[q] = 0.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       S1[q][a] = 0.f;
@@ -510,7 +549,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int rt = j / KQ, q = j % KQ;
         const int jn = j + 1, rtn = jn / KQ, qn = jn % KQ;
         if (jn < NG && qn == 0) load_tile(rtn, rtn & 1);
-        f32x4 nrm;
+        float nrm[4];
+        Row16Sum4 rs;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           if (jn < NG) mfma_step(qn, rtn & 1, m, zn);
@@ -523,19 +563,16 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             nrm[m] = fmaf(u1, u1, u0 * u0);
           } else {
-            // |u|^2 of row 16 rt + 4 g + i: sum over the 16 lanes that hold its output dims, one butterfly step
-            // of all four rows per slot (independent instructions: no wait states between them)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              nrm[i] = m == 4 ? row16_sum_step<0>(nrm[i]) : m == 5 ? row16_sum_step<1>(nrm[i])
-                     : m == 6 ? row16_sum_step<2>(nrm[i]) : row16_sum_step<3>(nrm[i]);
+            // |u|^2 of row 16 rt + 4 g + i: sum over the 16 lanes that hold its output dims, one step per slot;
+            // afterwards the lanes of bank b hold row 4 g + b
+            if (m == 4) rs.step0(nrm);
+            else if (m == 5) rs.step1();
+            else if (m == 6) rs.step2();
+            else rs.step3();
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (ln == 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) al[wave + FW * q][16 * rt + 4 * g + i] = cq[q] - 0.5f * nrm[i];
-        }
+        if ((ln & 3) == 0) al[wave + FW * q][16 * rt + 4 * g + (ln >> 2)] = cq[q] - 0.5f * rs.d0;
         if (jn < NG) { zc[0] = zn[0]; zc[1] = zn[1]; }
       }
     }
@@ -565,10 +602,17 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
         // the gradient sums instead of turning them into NaN; its log-density is already counted
         const float lsev = valid ? lse : INFINITY;
-        if (v0) sq[kp][row] = (a0 > cks[kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a0 - lsev));
-        if (v1)
-          sq[KQ == 2 ? kp + FW : kp][row] =
-              (a1 > cks[KQ == 2 ? kp + FW : kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a1 - lsev));
+        if (v0) {
+          const float s = (a0 > cks[kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a0 - lsev));
+          sq[kp][row] = s;
+          S0a = fmaf(s, s, S0a);
+        }
+        if (v1) {
+          const float s = (a1 > cks[KQ == 2 ? kp + FW : kp] - 1.5e9f ? 1.f : 0.f) *
+                          __builtin_amdgcn_exp2f(0.72134752f * (a1 - lsev));
+          sq[KQ == 2 ? kp + FW : kp][row] = s;
+          S0b = fmaf(s, s, S0b);
+        }
       }
     }
     if (GRAD) __syncthreads();
@@ -584,7 +628,6 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           for (int j = 0; j < 8; ++j) {
             const int row = 32 * m + 16 * (j >> 2) + 4 * g + (j & 3);
             sr[j] = sq[k][row];
-            S0[q] = fmaf(sr[j], sr[j], S0[q]);
           }
           f16x8 wh[2], wl[2];
 #pragma unroll
@@ -626,11 +669,6 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
     const int k = wave + FW * q;
     if (k < K) {
-      // S0: every lane of a 16-lane row holds the same rows; take one lane per row, add the 4 groups
-      float s0 = S0[q];
-      s0 += __shfl_xor(s0, 16, 64);
-      s0 += __shfl_xor(s0, 32, 64);
-      if (lane == 0) out[(int64_t)k * Q] = s0;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         float s1 = S1[q][nt];
@@ -646,7 +684,27 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
   }
   if ((lane >> 3) == 0) lpw[8 * wave + (lane & 7)] = (float)logp_acc;   // the lanes that summed rows 8 w + (0..7)
+  if (GRAD) {
+    // S0: add the eight row lanes of a component, then the waves (the tile buffers are free by now)
+    float* s0w = reinterpret_cast<float*>(&al[0][0]);          // [FW][2 * FW]
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+      S0a += __shfl_xor(S0a, off, 64);
+      S0b += __shfl_xor(S0b, off, 64);
+    }
+    __syncthreads();
+    if ((lane & 7) == 0) {
+      s0w[wave * 2 * FW + (lane >> 3)] = S0a;
+      s0w[wave * 2 * FW + FW + (lane >> 3)] = S0b;
+    }
+  }
   __syncthreads();
+  if (GRAD && tid < K) {
+    const float* s0w = reinterpret_cast<const float*>(&al[0][0]);
+    float s = 0.f;
+    for (int w = 0; w < FW; ++w) s += s0w[w * 2 * FW + tid];
+    out[(int64_t)tid * Q] = s;
+  }
   if (tid == 0) {
     float s = 0.f;
     for (int i = 0; i < FT; ++i) s += lpw[i];
