@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
           for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = a; b < 2; ++b) {      // S2 is symmetric: tile (1, 0) is the transpose of (0, 1)
               S2[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], wh[b], S2[q][a][b], 0, 0, 0);
               S2[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[a], wh[b], S2[q][a][b], 0, 0, 0);
               S2[q][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], wl[b], S2[q][a][b], 0, 0, 0);
@@ -676,10 +676,12 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         s1 += __shfl_xor(s1, 32, 64);
         if (g == 0) out[(int64_t)k * Q + 1 + 16 * nt + ln] = s1;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = nt; b < 2; ++b)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i) {
             out[(int64_t)k * Q + 1 + DP + (16 * nt + 4 * g + i) * DP + 16 * b + ln] = S2[q][nt][b][i];
+            if (b != nt) out[(int64_t)k * Q + 1 + DP + (16 * b + ln) * DP + 16 * nt + 4 * g + i] = S2[q][nt][b][i];
+          }
       }
     }
   }
