@@ -283,13 +283,15 @@ __device__ __forceinline__ float row16_sum_step(float v) {
 // Sums of four values over the 16 lanes of a DPP row in 8 instead of 16 lane-crossing adds: the first two steps fold
 // across the row's four banks of four lanes and halve the number of values each time (bank masks pick which value a
 // bank keeps), the last two run inside a bank.  After step 3 every lane of bank b holds the sum of v[b].  One call
-// per step so that the caller can put other work between them; the s_nop covers the two wait states a lane-crossing
-// read needs after the write of its source, which the assembler does not insert inside an asm statement.
+// per step so that the caller can put other work between them.  A lane-crossing read needs two wait states after the
+// write of its source, which the assembler does not insert around an asm statement: PAD = true pads them with an
+// s_nop, PAD = false is for callers that have at least two other instructions between the steps.
 struct Row16Sum4 {
   float d0, d1;
+  template <bool PAD>
   __device__ __forceinline__ void step0(const float (&v)[4]) {   // lanes L and 15 - L: banks 0, 1 keep v0, v1; 2, 3 keep v2, v3
+    if (PAD) asm volatile("s_nop 1");
     asm volatile(
-        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
@@ -297,27 +299,45 @@ struct Row16Sum4 {
         : "=&v"(d0), "=&v"(d1)
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
   }
+  template <bool PAD>
   __device__ __forceinline__ void step1() {                      // lanes L and 7 - L of a half row: bank b keeps v[b]
     float e;
+    if (PAD) asm volatile("s_nop 1");
     asm volatile(
-        "s_nop 1\n\t"
         "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa"
         : "=&v"(e)
         : "v"(d0), "v"(d1));
     d0 = e;
   }
+  template <bool PAD>
   __device__ __forceinline__ void step2() {
     float e;
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(e) : "v"(d0));
+    if (PAD) asm volatile("s_nop 1");
+    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(e) : "v"(d0));
     d0 = e;
   }
+  template <bool PAD>
   __device__ __forceinline__ void step3() {
     float e;
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(e) : "v"(d0));
+    if (PAD) asm volatile("s_nop 1");
+    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(e) : "v"(d0));
     d0 = e;
   }
+  template <bool PAD>
+  __device__ __forceinline__ void step(int k, const float (&v)[4]) {
+    if (k == 0) step0<PAD>(v);
+    else if (k == 1) step1<PAD>();
+    else if (k == 2) step2<PAD>();
+    else step3<PAD>();
+  }
 };
+
+// the value of lane L ^ 1 (CTRL 0xB1), L ^ 2 (0x4E) or 7 - L within each group of eight lanes (0x141)
+template <int CTRL>
+__device__ __forceinline__ float lane_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 
 // sum over the 16 lanes of a DPP row, result in every lane
 __device__ __forceinline__ float row16_sum(float v) {
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(256) void fullcov_colstats_final(const double* __re
 
 // GRAD = false (value only, what random-walk Metropolis asks for): no responsibilities, no raw sums
 template <int KQ, bool GRAD>  // components per wave (K <= FW * KQ)
-__global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2))) void fullcov_f16_kernel(
+__global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD ? 2 : 4))) void fullcov_f16_kernel(
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
     const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials) {
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   f32x4 S2[KQ][2][2];
   float S1[KQ][2];
-  float S0a = 0.f, S0b = 0.f;                 // sum of rho for components lane >> 3 (and + FW) over rows 8 wave + (lane & 7)
+  float S0a = 0.f, S0b = 0.f;                 // sum of rho for components lane & 7 (and + FW) over rows 8 wave + (lane >> 3)
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
 #pragma unroll
@@ -513,6 +533,12 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   __syncthreads();
   int buf = 0;
+#ifdef BVI_FC_TIMING
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define FC_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define FC_STAMP(i)
+#endif
   for (; tile < ntiles; tile += gridDim.x) {
     if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
     const unsigned char* yh = ybuf[buf][0];
@@ -541,6 +567,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const f32x4 c0 = {zb[q][nt], zb[q][nt], zb[q][nt], zb[q][nt]};
         z[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yv, av, pr == 0 ? c0 : z[nt], 0, 0, 0);
       };
+      float nrm[2][4];
+      Row16Sum4 rs;
       load_tile(0, 0);
 #pragma unroll
       for (int m = 0; m < 8; ++m) mfma_step(0, 0, m, zc);
@@ -549,52 +577,82 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int rt = j / KQ, q = j % KQ;
         const int jn = j + 1, rtn = jn / KQ, qn = jn % KQ;
         if (jn < NG && qn == 0) load_tile(rtn, rtn & 1);
-        float nrm[4];
-        Row16Sum4 rs;
+        // Value only: the row sums of group j - 1 ride in the odd slots of group j (no padding; measured faster
+        // at four waves per SIMD).  With the gradient (two waves per SIMD) the padded steps in the group's own
+        // slots measured faster.
+        if constexpr (!GRAD) {
+          // even slots: u and its squares for one row of group j; odd slots: one step of the row sums of group j - 1
+          // (lane-crossing adds: the vector work of the slots between them covers their wait states)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          if (jn < NG) mfma_step(qn, rtn & 1, m, zn);
-          if (m < 4) {
-            const float u0 = fmaf(zc[0][m], inv_t[q], -bl[q][0]);
-            const float u1 = fmaf(zc[1][m], inv_t[q], -bl[q][1]);
-            if (GRAD) {
-              u[GRAD ? q : 0][rt][0][m] = u0;
-              u[GRAD ? q : 0][rt][1][m] = u1;
+          for (int m = 0; m < 8; ++m) {
+            if (jn < NG) mfma_step(qn, rtn & 1, m, zn);
+            if ((m & 1) == 0) {
+              const int i = m >> 1;
+              const float u0 = fmaf(zc[0][i], inv_t[q], -bl[q][0]);
+              const float u1 = fmaf(zc[1][i], inv_t[q], -bl[q][1]);
+              if (GRAD) {
+                u[GRAD ? q : 0][rt][0][i] = u0;
+                u[GRAD ? q : 0][rt][1][i] = u1;
+              }
+              nrm[j & 1][i] = fmaf(u1, u1, u0 * u0);
+            } else if (j > 0) {
+              rs.template step<false>(m >> 1, nrm[(j - 1) & 1]);
             }
-            nrm[m] = fmaf(u1, u1, u0 * u0);
-          } else {
-            // |u|^2 of row 16 rt + 4 g + i: sum over the 16 lanes that hold its output dims, one step per slot;
-            // afterwards the lanes of bank b hold row 4 g + b
-            if (m == 4) rs.step0(nrm);
-            else if (m == 5) rs.step1();
-            else if (m == 6) rs.step2();
-            else rs.step3();
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          // |u|^2 of row 16 rt + 4 g + b is now in the lanes of bank b
+          if (j > 0 && (ln & 3) == 0)
+            al[wave + FW * ((j - 1) % KQ)][16 * ((j - 1) / KQ) + 4 * g + (ln >> 2)] = cq[(j - 1) % KQ] - 0.5f * rs.d0;
+        } else {
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            if (jn < NG) mfma_step(qn, rtn & 1, m, zn);
+            if (m < 4) {
+              const float u0 = fmaf(zc[0][m], inv_t[q], -bl[q][0]);
+              const float u1 = fmaf(zc[1][m], inv_t[q], -bl[q][1]);
+              if (GRAD) {
+                u[GRAD ? q : 0][rt][0][m] = u0;
+                u[GRAD ? q : 0][rt][1][m] = u1;
+              }
+              nrm[0][m] = fmaf(u1, u1, u0 * u0);
+            } else {
+              rs.template step<true>(m - 4, nrm[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if ((ln & 3) == 0) al[wave + FW * q][16 * rt + 4 * g + (ln >> 2)] = cq[q] - 0.5f * rs.d0;
         }
-        if ((ln & 3) == 0) al[wave + FW * q][16 * rt + 4 * g + (ln >> 2)] = cq[q] - 0.5f * rs.d0;
         if (jn < NG) { zc[0] = zn[0]; zc[1] = zn[1]; }
       }
+      if constexpr (!GRAD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rs.template step<true>(k, nrm[(NG - 1) & 1]);
+        if ((ln & 3) == 0)
+          al[wave + FW * ((NG - 1) % KQ)][16 * ((NG - 1) / KQ) + 4 * g + (ln >> 2)] = cq[(NG - 1) % KQ] - 0.5f * rs.d0;
+      }
     }
+    FC_STAMP(0)
     __syncthreads();
+    FC_STAMP(1)
     {
       // log-sum-exp over the components and sqrt(rho_ik) = exp((a_ik - lse) / 2), shared out over the workgroup: wave w
-      // takes rows 8 w .. 8 w + 7, lane = (row, component pair kp and kp + 8); maxima and sums cross the eight
-      // component lanes of a row with three lane exchanges.  Every (row, component) is exponentiated once per
-      // tile -- when every wave did all 64 rows for itself, the K exponentials per lane were a seventh of the
-      // kernel's vector work.
-      const int rl = lane & 7, kp = lane >> 3, row = 8 * wave + rl;
+      // takes rows 8 w .. 8 w + 7, lane = (component pair kp and kp + 8, row); maxima and sums cross the eight
+      // neighbouring component lanes of a row with three DPP exchanges (a few cycles each; through ds_bpermute the
+      // six dependent exchanges were a tenth of the tile's time, both waves of a SIMD sitting in them together).
+      // Every (row, component) is exponentiated once per tile -- when every wave did all 64 rows for itself, the
+      // K exponentials per lane were a seventh of the kernel's vector work.
+      const int kp = lane & 7, rl = lane >> 3, row = 8 * wave + rl;
       const bool v0 = kp < K, v1 = KQ == 2 && kp + FW < K;
       const float a0 = v0 ? al[kp][row] : -INFINITY;
       const float a1 = v1 ? al[KQ == 2 ? kp + FW : kp][row] : -INFINITY;
       float m = fmaxf(a0, a1);
-      m = fmaxf(m, __shfl_xor(m, 8, 64));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = fmaxf(m, lane_dpp<0xB1>(m));
+      m = fmaxf(m, lane_dpp<0x4E>(m));
+      m = fmaxf(m, lane_dpp<0x141>(m));
       float sm = __builtin_amdgcn_exp2f(1.44269504f * (a0 - m)) + __builtin_amdgcn_exp2f(1.44269504f * (a1 - m));
-      sm += __shfl_xor(sm, 8, 64);
-      sm += __shfl_xor(sm, 16, 64);
-      sm += __shfl_xor(sm, 32, 64);
+      sm += lane_dpp<0xB1>(sm);
+      sm += lane_dpp<0x4E>(sm);
+      sm += lane_dpp<0x141>(sm);
       const float lse = m + __logf(sm);
       const bool valid = tile * FT + row < n;
       if (kp == 0 && valid) logp_acc += (double)(lse - row_level);
@@ -615,7 +673,9 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
     }
+    FC_STAMP(2)
     if (GRAD) __syncthreads();
+    FC_STAMP(3)
     // ---- responsibilities and raw sums: w = sqrt(rho) u in two f16 pieces is both operand of S2 += W^T W ----
 #pragma unroll
     for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
@@ -656,10 +716,17 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
       }
     }
+    FC_STAMP(4)
     if (tile + gridDim.x < ntiles) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+    FC_STAMP(5)
   }
+#ifdef BVI_FC_TIMING
+  if (blockIdx.x == 1 && blockIdx.y == 3 && lane == 0 && (wave == 0 || wave == 5))
+    printf("wave %d phases (memtime ticks): gemm1 %llu bar1 %llu lse %llu bar2 %llu s2 %llu store+bar3 %llu\n", wave,
+           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
+#endif
 
   // ---- partials of this (row block, chain): [K][1 + DP + DP*DP] then the log-prob ----
   // S2 accumulator: lane holds rows (first index) 16 a + 4 g + i, column 16 b + ln
@@ -685,19 +752,19 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
   }
-  if ((lane >> 3) == 0) lpw[8 * wave + (lane & 7)] = (float)logp_acc;   // the lanes that summed rows 8 w + (0..7)
+  if ((lane & 7) == 0) lpw[8 * wave + (lane >> 3)] = (float)logp_acc;   // the lanes that summed rows 8 w + (0..7)
   if (GRAD) {
     // S0: add the eight row lanes of a component, then the waves (the tile buffers are free by now)
     float* s0w = reinterpret_cast<float*>(&al[0][0]);          // [FW][2 * FW]
 #pragma unroll
-    for (int off = 1; off <= 4; off <<= 1) {
+    for (int off = 8; off <= 32; off <<= 1) {
       S0a += __shfl_xor(S0a, off, 64);
       S0b += __shfl_xor(S0b, off, 64);
     }
     __syncthreads();
-    if ((lane & 7) == 0) {
-      s0w[wave * 2 * FW + (lane >> 3)] = S0a;
-      s0w[wave * 2 * FW + FW + (lane >> 3)] = S0b;
+    if (lane < 8) {
+      s0w[wave * 2 * FW + lane] = S0a;
+      s0w[wave * 2 * FW + FW + lane] = S0b;
     }
   }
   __syncthreads();
