@@ -533,12 +533,6 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   }
   __syncthreads();
   int buf = 0;
-#ifdef BVI_FC_TIMING
-  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define FC_STAMP(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[i] += tn - tlast; tlast = tn; }
-#else
-#define FC_STAMP(i)
-#endif
   for (; tile < ntiles; tile += gridDim.x) {
     if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
     const unsigned char* yh = ybuf[buf][0];
@@ -631,9 +625,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
           al[wave + FW * ((NG - 1) % KQ)][16 * ((NG - 1) / KQ) + 4 * g + (ln >> 2)] = cq[(NG - 1) % KQ] - 0.5f * rs.d0;
       }
     }
-    FC_STAMP(0)
     __syncthreads();
-    FC_STAMP(1)
     {
       // log-sum-exp over the components and sqrt(rho_ik) = exp((a_ik - lse) / 2), shared out over the workgroup: wave w
       // takes rows 8 w .. 8 w + 7, lane = (component pair kp and kp + 8, row); maxima and sums cross the eight
@@ -673,9 +665,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
         }
       }
     }
-    FC_STAMP(2)
     if (GRAD) __syncthreads();
-    FC_STAMP(3)
     // ---- responsibilities and raw sums: w = sqrt(rho) u in two f16 pieces is both operand of S2 += W^T W ----
 #pragma unroll
     for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
@@ -716,17 +706,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
         }
       }
     }
-    FC_STAMP(4)
     if (tile + gridDim.x < ntiles) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
-    FC_STAMP(5)
   }
-#ifdef BVI_FC_TIMING
-  if (blockIdx.x == 1 && blockIdx.y == 3 && lane == 0 && (wave == 0 || wave == 5))
-    printf("wave %d phases (memtime ticks): gemm1 %llu bar1 %llu lse %llu bar2 %llu s2 %llu store+bar3 %llu\n", wave,
-           tph[0], tph[1], tph[2], tph[3], tph[4], tph[5]);
-#endif
 
   // ---- partials of this (row block, chain): [K][1 + DP + DP*DP] then the log-prob ----
   // S2 accumulator: lane holds rows (first index) 16 a + 4 g + i, column 16 b + ln
