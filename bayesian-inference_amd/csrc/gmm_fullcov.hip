@@ -509,7 +509,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       for (int e = 0; e < 4; ++e) yraw[e] = t4[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) yraw[e] = (gr < n && sc4 + e < D) ? Y[gr * D + sc4 + e] : cm[e];
+      for (int e = 0; e < 4; ++e) {
+        yraw[e] = cm[e];
+        if (gr < n && sc4 + e < D) yraw[e] = Y[gr * D + sc4 + e];
+      }
     }
   };
   auto lstore = [&](int buf) {
