@@ -453,7 +453,7 @@ def test_gmm1d(nat, ws, gpu_device, k, c, n):
 
 
 @pytest.mark.parametrize('d,k,c,n', [(2, 4, 3, 100), (4, 3, 2, 25), (8, 5, 4, 1000), (32, 16, 2, 500), (32, 16, 5, 4099),
-                                     (16, 8, 7, 2000), (5, 1, 2, 64), (3, 2, 1, 17)])
+                                     (16, 8, 7, 2000), (5, 1, 2, 64), (3, 2, 1, 17), (32, 12, 3, 700), (16, 9, 2, 333)])
 def test_gmm_fullcov(nat, ws, gpu_device, d, k, c, n):
     rng = np.random.default_rng(17 * d + k + c + n)
     true_mu = rng.integers(-20, 21, (k, d)).astype(np.float64)
