@@ -200,9 +200,15 @@ class GaussianMixture1D(FusedLogLikelihood):
     exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15."""
     family = _native.FAMILY_GMM1D
 
-    def __init__(self, y, k, group=None):
+    def __init__(self, y, k, group=None, sort_rows=True):
         super().__init__(y.device, group)
         self.y = y.to(torch.float32).contiguous().reshape(-1)
+        if sort_rows:
+            # The rows are exchangeable, so their order is the layout's to choose: in ascending order neighbouring rows
+            # lie within reach of the same few components, which the kernels whose lanes hold several rows (up to 16
+            # chains) use to leave the others out (N = 100M, K = 8: 4 chains, value only 0.61 -> 0.34 ms; 16 chains
+            # 3.9 -> 2.9 ms).  Sums change in the last float digits only.
+            self.y = torch.sort(self.y).values.contiguous()
         self.n, self.k = self.y.shape[0], int(k)
         self.n_params = 3 * self.k
 

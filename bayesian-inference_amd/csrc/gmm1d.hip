@@ -148,6 +148,66 @@ __device__ __forceinline__ void mix_row(float yj, float keep, unsigned act, cons
   if (__builtin_expect(!near, 0)) mix_row_far<K, GRAD>(yj, keep, p, acc);
 }
 
+// Four rows per lane with one test per component for all four (the few-chain kernel, whose lanes hold rows: the
+// scalar test-and-branch per component costs as much as a component's arithmetic for one row).
+template <int K, bool GRAD>
+__device__ __forceinline__ void mix_rows4_skip(const float (&y)[4], unsigned act, const MixParams<K>& p,
+                                               float (&acc)[1 + 3 * K]) {
+  float u[GRAD ? K : 1][4], e[GRAD ? K : 1][4];
+  if (GRAD) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        asm volatile("" : "=v"(e[k][r]));
+        asm volatile("" : "=v"(u[k][r]));
+      }
+  }
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (act & (1u << k)) {
+      asm volatile("" ::);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float uu = (y[r] - p.mu[k]) * p.isg[k];
+        const float ee = __builtin_amdgcn_exp2f(fmaf(-uu, uu, p.Bp[k]));
+        ssum[r] += ee;
+        if (GRAD) { u[k][r] = uu; e[k][r] = ee; }
+      }
+    }
+  }
+  bool near[4];
+  float inv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    near[r] = ssum[r] >= kMixNear;
+    acc[0] += near[r] ? __builtin_amdgcn_logf(ssum[r]) : 0.f;
+    if (GRAD) inv[r] = near[r] ? __builtin_amdgcn_rcpf(ssum[r]) : 0.f;
+  }
+  if (GRAD) {
+    unsigned act2 = act;
+    asm volatile("" : "+s"(act2));
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (act2 & (1u << k)) {
+        asm volatile("" ::);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float rho = e[k][r] * inv[r];
+          const float ru = rho * u[k][r];
+          acc[1 + k] += rho;
+          acc[1 + K + k] += ru;
+          acc[1 + 2 * K + k] = fmaf(ru, u[k][r], acc[1 + 2 * K + k]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (__builtin_expect(!near[r], 0)) mix_row_far<K, GRAD>(y[r], 1.f, p, acc);
+}
+
 // Which components can matter at a given y, for the chains of one wave: the y axis between the outermost reaches
 // of the wave's components is cut into `nbins` bins, and tab[1 + b] holds a bit per component that is set unless,
 // for every chain of the wave, the whole bin (widened by a bin on each side, which covers the rounding of the bin
@@ -298,10 +358,33 @@ void gmm1d_kernel(const float* __restrict__ y, int64_t n, int kreal,
   mix_store_partials<K, CP, GRAD>(red, kreal, blockIdx.y * CP, C, partials);
 }
 
+// minimum (MAX = false) or maximum over the wave, as a wave-uniform value; NaNs are ignored unless all are NaN
+template <bool MAX>
+__device__ __forceinline__ float mix_wave_extreme(float v) {
+  auto comb = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  auto dpp = [](float x, auto ctrl, auto rows) {   // lanes the pattern does not reach keep their own value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value, decltype(rows)::value, 0xF, false));
+  };
+  using std::integral_constant;
+  v = comb(v, dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{}));    // lane ^ 1
+  v = comb(v, dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{}));    // lane ^ 2
+  v = comb(v, dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{}));   // 7 - lane within eight
+  v = comb(v, dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{}));   // 15 - lane within sixteen
+  v = comb(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{}));   // rows 1, 3 <- lane 15 of the row before
+  v = comb(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{}));   // rows 2, 3 <- lane 31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Few chains per group (CG = 1 or 4): every lane streams rows of its own with 16-byte loads and carries the
 // sums of all CG chains in registers; the chains' parameters are wave-uniform (scalar registers).  The shuffle
 // mapping above issues one 4-byte load per lane and iteration, which leaves too little in flight when the
-// per-row work is small (one or a few chains).  Lanes hold different rows here, so no component is skipped.
+// per-row work is small (one or a few chains).  Lanes hold different rows here, so a component can be left out
+// only if it is out of reach (exponent below -kMixSkip, as in MixTable) of all 256 rows a wave has loaded: the
+// wave takes the minimum and maximum of those rows (12 lane-crossing operations) and lane g K + k compares them
+// with the reach of component k of chain g -- one ballot gives the active sets of all chains.  That happens when
+// neighbouring rows hold similar values, i.e. when the caller has stored the rows in ascending order (the host
+// layer does; any order is correct).  A wave whose rows span every component takes the branch-free form.
 template <int K, int CG, bool GRAD>
 __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict__ y, int64_t n, int kreal,
                                                          const float* __restrict__ theta, int C,
@@ -318,10 +401,58 @@ __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[g][q] = 0.f;
   float rows = 0.f;
-  auto row = [&](float yj) {
+  auto row = [&](float yj) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = 0; g < CG; ++g) mix_row<K, GRAD, false>(yj, 1.f, 0u, p[g], acc[g]);
     rows += 1.f;
+  };
+  // reach of this lane's (chain, component): [lo, hi] is where the exponent is above -kMixSkip.  Lanes beyond
+  // CG * K hold an empty interval; non-finite parameters give NaN, which compares as "in reach".
+  __shared__ float reach_lo[64], reach_hi[64];
+  if (threadIdx.x < 64) { reach_lo[threadIdx.x] = INFINITY; reach_hi[threadIdx.x] = -INFINITY; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int g = 0; g < CG; ++g)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k < kreal) {
+          const float r = sqrtf(fmaxf(kMixSkip + p[g].Bp[k], 0.f)) / p[g].isg[k] * 1.0001f;
+          reach_lo[g * K + k] = p[g].mu[k] - r;
+          reach_hi[g * K + k] = p[g].mu[k] + r;
+        }
+  }
+  __syncthreads();
+  const float my_lo = reach_lo[threadIdx.x & 63], my_hi = reach_hi[threadIdx.x & 63];
+  constexpr unsigned long long kAll = CG * K == 64 ? ~0ull : ((1ull << (CG * K)) - 1ull);
+  unsigned long long all_real = 0;
+#pragma unroll
+  for (int g = 0; g < CG; ++g) all_real |= (unsigned long long)((1u << kreal) - 1u) << (g * K);
+  // With the gradient and four chains the two forms together need every register there is and the skipping form
+  // then costs more than it saves (measured, rows in ascending order: 1.24 ms against 1.06 at N = 100M, K = 8):
+  // those launches evaluate every component.
+  constexpr bool kRange = !(GRAD && CG > 1);
+  bool probing = kRange;     // wave-uniform: cleared by the first group of rows that spans every component
+  auto rows4 = [&](const f32x4& v) __attribute__((always_inline)) {
+    if (!probing) {
+      row(v.x); row(v.y); row(v.z); row(v.w);
+      return;
+    }
+    const float lmin = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), lmax = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    const float ymin = mix_wave_extreme<false>(lmin), ymax = mix_wave_extreme<true>(lmax);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(!(my_hi < ymin || my_lo > ymax)) & kAll;
+    if ((act & all_real) == all_real) {
+      probing = false;       // rows in no particular order: stop looking
+      row(v.x); row(v.y); row(v.z); row(v.w);
+    } else {
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const unsigned ag = (unsigned)(act >> (g * K)) & ((1u << K) - 1u);
+        const float yr[4] = {v.x, v.y, v.z, v.w};
+        mix_rows4_skip<K, GRAD>(yr, ag, p[g], acc[g]);
+      }
+      rows += 4.f;
+    }
   };
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   int64_t head = (int64_t)(((16 - ((uintptr_t)y & 15)) & 15) >> 2);
@@ -329,10 +460,11 @@ __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict
   const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>(y + head);
   const int64_t n4 = (n - head) >> 2, tail0 = head + 4 * n4;
   int64_t i = tid;
-  for (; i + nth < n4; i += 2 * nth) {
+  // whole waves only (the lane-crossing steps of rows4 want all 64 lanes): the wave's last lane decides
+  for (; i + (63 - (threadIdx.x & 63)) + nth < n4; i += 2 * nth) {
     const f32x4 v0 = y4[i], v1 = y4[i + nth];
-    row(v0.x); row(v0.y); row(v0.z); row(v0.w);
-    row(v1.x); row(v1.y); row(v1.z); row(v1.w);
+    rows4(v0);
+    rows4(v1);
   }
   for (; i < n4; i += nth) {
     const f32x4 v = y4[i];

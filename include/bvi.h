@@ -177,7 +177,10 @@ int bvi_linreg_packed_logp_grad(const void* packed, int64_t n, int d, int format
 /* Univariate Gaussian mixture: y[n], theta[C,3k] = (weights_k, loc_k, scale_k)
  * -> logp[C], grad[C,3k].  Weights are normalised by their sum, as
  * Categorical(probs=weights) does.  Replaces the likelihood node for
- * exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15. */
+ * exploratory_experiments/univariate-gaussian-mixture-test.ipynb cell 15.
+ * The rows may come in any order.  A caller that keeps them in ascending order lets launches of up to 16 chains
+ * leave out the components that are out of reach of a whole group of neighbouring rows (the shipped host layer
+ * sorts its copy once; the sums then differ from those over another order in the last float digits). */
 int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, int n_chains,
                         float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes, void* stream);
 

@@ -332,6 +332,54 @@ def test_mixture_component_table(nat, ws, gpu_device, n, case):
     assert torch.equal(lpb[[0, 2, c - 1]], lp[[0, 2, c - 1]])
 
 
+@pytest.mark.parametrize('c', [1, 3])
+@pytest.mark.parametrize('case', ['separated', 'overlapping', 'k16'])
+def test_mixture_few_chains_rows_in_ascending_order(nat, ws, gpu_device, c, case):
+    """The few-chain kernel (lanes hold rows) leaves a component out for the 256 rows a wave has loaded when all of
+    them are out of its reach, which happens when the rows are stored in ascending order (what the host layer does).
+    Same inputs in ascending and in the original order, against float64: separated components (most are left out),
+    overlapping ones (none is), K = 16 (one chain per group), a stretch of rows no component reaches, a NaN row's
+    worth of propagation, one chain with a NaN mean; the value-only launch returns the same log densities."""
+    n = 5_000_011
+    g = torch.Generator(device=gpu_device); g.manual_seed(23)
+    k = {'separated': 8, 'overlapping': 6, 'k16': 16}[case]
+    if case == 'overlapping':
+        locs = torch.linspace(-2, 2, k, device=gpu_device)
+        wbase = torch.tensor([0.01, 0.6, 0.05, 0.2, 0.04, 0.1], device=gpu_device)
+        sbase = torch.tensor([0.2, 1.0, 5.0, 0.5, 2.0, 0.3], device=gpu_device)
+    else:
+        locs = torch.linspace(-20, 20, k, device=gpu_device)
+        wbase = torch.full((k,), 1.0 / k, device=gpu_device)
+        sbase = torch.ones(k, device=gpu_device)
+    comp = torch.multinomial(wbase, n, replacement=True, generator=g)
+    y = locs[comp] + sbase[comp] * torch.randn(n, generator=g, device=gpu_device)
+    del comp
+    y[::100_003] = 1000.0            # rows no component reaches: a stretch of them at the upper end once sorted
+    y[11::300_017] = 2.857
+    th = torch.cat([wbase * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device)),
+                    locs + 0.1 * torch.randn(c, k, generator=g, device=gpu_device),
+                    sbase * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device))], -1).contiguous()
+    ys = torch.sort(y).values.contiguous()
+    ref_lp, ref_g, absg = _mixture_float64(ys, th, k)
+    for rows, what in ((ys, 'ascending'), (y, 'as drawn')):
+        lp, gr = nat.gmm1d_logp_grad(rows, th, k, ws)
+        lpv, _ = nat.gmm1d_logp_grad(rows, th, k, ws, want_grad=False)
+        _close(lp, ref_lp, ref_lp.abs(), what='mixture logp, %d chains, rows %s (%s)' % (c, what, case))
+        _close(lpv, ref_lp, ref_lp.abs(), what='mixture logp, value only, %d chains, rows %s (%s)' % (c, what, case))
+        _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg,
+               what='mixture grad, %d chains, rows %s (%s)' % (c, what, case))
+    # an odd start (the 16-byte grid of the loads shifts) and non-finite inputs
+    lpo, _ = nat.gmm1d_logp_grad(ys[1:], th, k, ws, want_grad=False)
+    ref_o, _, _ = _mixture_float64(ys[1:], th, k)
+    _close(lpo, ref_o, ref_o.abs(), what='mixture logp, odd start')
+    bad = th.clone(); bad[0, k + 1] = float('nan')
+    lpb, grb = nat.gmm1d_logp_grad(ys, bad, k, ws)
+    assert bool(torch.isnan(lpb[0])) and bool(torch.isfinite(lpb[1:]).all())
+    ynan = ys.clone(); ynan[n // 2] = float('nan')
+    lpn, _ = nat.gmm1d_logp_grad(ynan, th, k, ws, want_grad=False)
+    assert bool(torch.isnan(lpn).all())
+
+
 def test_mixture_100m_rows(nat, ws, gpu_device):
     """BASELINE.json configs[2] size: K = 8 mixture over 100M rows.  Row shards (cut at an odd row, so the
     second shard is not 16-byte aligned) add up; two chains against a chunked float64 evaluation."""

@@ -11,6 +11,7 @@ ap.add_argument('--k', type=int, default=8)
 ap.add_argument('--lib', default=None)
 ap.add_argument('--chains', type=int, nargs='*', default=[1, 4, 16, 64, 256, 1024])
 ap.add_argument('--only', default=None)
+ap.add_argument('--sorted', action='store_true', help='rows in ascending order (what the host layer stores)')
 a = ap.parse_args()
 if a.lib:
     nat._LIB_PATH = os.path.abspath(a.lib)
@@ -21,6 +22,8 @@ locs = torch.linspace(-20, 20, k, device=dev)
 comp = torch.randint(0, k, (a.rows,), generator=g, device=dev)
 y = locs[comp] + torch.randn(a.rows, generator=g, device=dev)
 del comp
+if a.sorted:
+    y = torch.sort(y).values.contiguous()
 for c in a.chains:
     th = torch.cat([torch.full((c, k), 1.0 / k, device=dev) * (1 + 0.1 * torch.rand(c, k, generator=g, device=dev)),
                     locs + 0.1 * torch.randn(c, k, generator=g, device=dev),
