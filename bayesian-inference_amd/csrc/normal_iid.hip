@@ -44,24 +44,28 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
   float s1 = 0.f;
   double s2 = 0.0;
   int rows = 0;
+  double ysum = 0.0;       // lane l: sum of row l of every full tile this wave has taken (CP = 64)
+  int rows_full = 0;       // rows of those tiles
   const int64_t ntiles = (n + 63) / 64;
   for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
     float a1 = 0.f, a2 = 0.f;
     if (CP == 64 && t * 64 + 64 <= n) {
       // lane = chain: every lane needs the same 64 rows, so they come through the scalar data path
       // (wave-uniform address, read-only data) and reach the vector ALU as scalar operands -- no LDS
-      // round trip per row, three vector instructions per (row, chain)
+      // round trip per row, two vector instructions per (row, chain): the residual and its square.  The sum of
+      // the residuals themselves needs no per-chain work: sum_i (y_i - mu) = sum_i y_i - rows * mu, and sum_i y_i
+      // is the same for every chain -- one vector load and one add per tile, row l of the tile in lane l.
       const float* __restrict__ yt = y + t * 64;
-      float b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;   // four independent chains
+      ysum += (double)yt[lane];
+      float b2 = 0.f, c2 = 0.f, d2 = 0.f;   // four independent chains of fmas
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const float r0 = yt[j] - mu, r1 = yt[16 + j] - mu, r2 = yt[32 + j] - mu, r3 = yt[48 + j] - mu;
-        a1 += r0; b1 += r1; c1 += r2; d1 += r3;
         a2 = fmaf(r0, r0, a2); b2 = fmaf(r1, r1, b2); c2 = fmaf(r2, r2, c2); d2 = fmaf(r3, r3, d2);
       }
-      s1 += (a1 + b1) + (c1 + d1);
       s2 += (double)((a2 + b2) + (c2 + d2));
       rows += 64;
+      rows_full += 64;
       continue;
     }
     const int64_t i = t * 64 + lane;
@@ -88,6 +92,11 @@ __global__ __launch_bounds__(256) void normal_iid_kernel(const float* __restrict
     }
     s1 += a1;
     s2 += (double)a2;
+  }
+  if (CP == 64) {   // the full tiles' share of S1 (exact in double: mu has 12 mantissa bits, rows_full < 2^31)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ysum += __shfl_xor(ysum, off, 64);
+    s1 += (float)(ysum - (double)rows_full * (double)mu);
   }
   s1 = bvi_reduce_over_rowsubs<CP>(s1);
   const float s2c = bvi_reduce_over_rowsubs<CP>((float)(s2 - (double)rows * sig2));
