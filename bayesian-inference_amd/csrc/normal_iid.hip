@@ -139,11 +139,13 @@ __global__ __launch_bounds__(256) void normal_iid_rows_kernel(const float* __res
     s1[k] = 0.f;
     s2[k] = 0.f;
   }
+  // The residuals are summed for the group's first chain only: sum_i (y_i - mu_k) = sum_i (y_i - mu_0) +
+  // rows (mu_0 - mu_k), exact in double (the mu have 12 mantissa bits) -- 2 CG + 1 instead of 3 CG operations per row.
   auto row = [&](float yv) {
 #pragma unroll
     for (int k = 0; k < CG; ++k) {
       const float r = yv - mu[k];
-      s1[k] += r;
+      if (k == 0) s1[0] += r;
       s2[k] = fmaf(r, r, s2[k]);
     }
   };
@@ -179,7 +181,8 @@ __global__ __launch_bounds__(256) void normal_iid_rows_kernel(const float* __res
 #pragma unroll
   for (int k = 0; k < CG; ++k) {
     const double sc = c0 + k < C ? (double)theta[2 * (c0 + k) + 1] : 0.0;
-    const float t1 = bvi_reduce_over_rowsubs<1>(s1[k]);
+    const float t1 = bvi_reduce_over_rowsubs<1>(
+        k == 0 ? s1[0] : (float)((double)s1[0] + rows * ((double)mu[0] - (double)mu[k])));
     const float t2 = bvi_reduce_over_rowsubs<1>((float)((double)s2[k] - rows * sc * sc));
     if (lane == 0) {
       sm[wave][k][0] = t1;
