@@ -69,7 +69,7 @@
 namespace {
 
 constexpr int kTileRows = 128;             // rows staged per barrier; processed as 64-row halves
-constexpr int kGramOffset = 1024;                       // X^T X, [64][64] double, behind the Header struct
+constexpr int kGramOffset = 1280;                       // X^T X, [64][64] double, behind the Header struct
 constexpr int kLowOffset = kGramOffset + 64 * 64 * 8;   // A [64][64], Bt [64][64], XR^T y [64], XR^T 1 [64], double
 constexpr int kLowStride = 2 * 64 * 64 + 128;
 constexpr int kHeader = kLowOffset + kLowStride * 8;    // everything in front of the planes
@@ -81,11 +81,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct Header {
-  float colscale[64];
-  double colsum[64];
+  float colscale[64];   // of the centred columns x - shift
+  double colsum[64];    // sum_i (x_id - shift_d), exact differences summed in double
   double ysum;
   float ymax;     // max_i |y_i - ybar|
   float ybar;     // mean of y in f32: the kernels work on y - ybar and on the intercept b0 - ybar
+  float shift[64];      // the column means in f32: every sum of the format is taken over x - shift
 };
 static_assert(sizeof(Header) <= kGramOffset, "header must fit");
 
@@ -115,10 +116,29 @@ __device__ __forceinline__ float chain_scale(float amax_v, float b0, float ymax,
   return ldexpf(1.f, min(max(14 - ilogbf(bound), -126), 126));
 }
 
+// The columns are centred at pack time (x~ = x - shift, shift = the column means in f32), so the model reads
+//   y - b0 - x . w = (y - ybar) - (b0 - ybar + shift . w) - x~ . w:
+// the intercept the kernels and the finalize kernel work with is the chain's fitted value at the centroid of the
+// data relative to ybar.  Summed in this fixed order wherever it is needed (the finalize kernel has to reproduce the
+// kernels' float bit for bit; what the float leaves of the exact value is carried in closed form there).
+__device__ __forceinline__ float centred_intercept(const float* __restrict__ th, const float* __restrict__ shift,
+                                                   int dr, float ybar) {
+  float acc = th[0] - ybar;
+  for (int f = 0; f < dr; ++f) acc = fmaf(shift[f], th[1 + f], acc);
+  return acc;
+}
+
+// Scaled entry of the centred plane before its rounding to f16: the exact difference x - shift, times the column's
+// power-of-two scale, rounded to float once (pack, Gram and remainder kernels all go through here)
+__device__ __forceinline__ float plane_value(float x, float shift, float colscale) {
+  return (float)(((double)x - (double)shift) * (double)colscale);
+}
+
 // Target value given to the padding rows of the last tile: the centred intercept of the first chain of the
 // workgroup's chain block (0 if that is not finite)
-__device__ __forceinline__ float pad_target(const float* __restrict__ theta, int first_chain, int dr, float ybar) {
-  const float v = theta[(int64_t)first_chain * (dr + 2)] - ybar;
+__device__ __forceinline__ float pad_target(const float* __restrict__ theta, const float* __restrict__ shift,
+                                            int first_chain, int dr, float ybar) {
+  const float v = centred_intercept(theta + (int64_t)first_chain * (dr + 2), shift, dr, ybar);
   return isfinite(v) ? v : 0.f;
 }
 
@@ -205,7 +225,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
         }
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));   // the four lane groups hold the chain's D features
       amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-      const float b0 = cvalid ? th[0] - hdr->ybar : 0.f;      // the intercept against the centred targets
+      // the intercept against the centred targets and columns
+      const float b0 = cvalid ? centred_intercept(th, hdr->shift, dr, hdr->ybar) : 0.f;
       const float t = chain_scale(amax, b0, hdr->ymax, D);
       float grid, ginv;
       piece_grid(amax * t, grid, ginv);
@@ -241,7 +262,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   float yp;
   bool yvalid;
   const float ybar = hdr->ybar;
-  const float ypad = pad_target(theta, cbi * (16 * CT * NW), dr, ybar);
+  const float ypad = pad_target(theta, hdr->shift, cbi * (16 * CT * NW), dr, ybar);
   auto gload = [&](int64_t tile) {
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
 #pragma unroll
@@ -271,6 +292,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid ? yp - ybar : ypad;
   };
 
+  // slot behind the partials that tells the finalize kernel how this chain block was scaled: 0 = one scale per chain
+  if (rbi == 0 && tid == 0) partials[(int64_t)nrb * C * (dr + 2) + cbi] = 0.f;
   int64_t tile = rbi;
   if (tile < ntiles) {
     gload(tile);
@@ -454,37 +477,78 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const unsigned char* planes = packed + kHeader;
   const unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
 
+  // Scales.  Each chain has its natural power-of-two scale t_c (chain_scale: the largest that keeps its scaled
+  // residuals inside the f16 range).  When the natural scales of the workgroup's chains lie within 2^8 of each other
+  // -- chains of one run do -- the whole block works with ONE scale T, the smallest of them, and with no intercept:
+  // the staged targets are T (y - ybar), the same numbers for every chain, and enter the residual product as its
+  // accumulator (no vector instruction per residual); with the columns centred at pack time the intercept
+  // b0 - ybar + shift . w is orthogonal to everything the pass sums (S2 = S2_k + n db^2 up to the plane's remainders:
+  // nothing cancels) and the finalize kernel adds it in closed form, as it adds the remainders of W.  A block whose
+  // chains are further apart (a chain on its way to infinity next to settled ones) keeps one scale and one
+  // intercept per chain and pays one fma per residual for the targets.
+  __shared__ float sred[2 * NW];
   f16x8 w1[CT][KS];
   float tc[CT];
   f32x4v nb0v[CT];
+  float T;
+  bool uni;
+  {
+    float v[CT][KS][8], amaxc[CT], b0c[CT];
+    float tlo = INFINITY, thi = 0.f;
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    const int chain = cbase + 16 * ct + ln;
-    const bool cvalid = chain < C;
-    const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
-    float v[KS][8], amax = 0.f;
+    for (int ct = 0; ct < CT; ++ct) {
+      const int chain = cbase + 16 * ct + ln;
+      const bool cvalid = chain < C;
+      const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
+      float amax = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int f = 32 * ks + 8 * g + j;
-        v[ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
-        amax = fmaxf(amax, fabsf(v[ks][j]));
+        for (int j = 0; j < 8; ++j) {
+          const int f = 32 * ks + 8 * g + j;
+          v[ct][ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
+          amax = fmaxf(amax, fabsf(v[ct][ks][j]));
+        }
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      amaxc[ct] = amax;
+      b0c[ct] = cvalid ? centred_intercept(th, hdr->shift, dr, hdr->ybar) : 0.f;
+      // the chain's scale without an intercept; chains whose bound is not finite (they return NaN whatever the
+      // scale) and lanes beyond the last chain take no part in the block's choice
+      const float bound = hdr->ymax + (float)D * (float)(2 << kColTop) * amax;
+      if (cvalid && bound > 0.f && isfinite(bound)) {
+        const float tn = chain_scale(amax, 0.f, hdr->ymax, D);
+        tlo = fminf(tlo, tn);
+        thi = fmaxf(thi, tn);
       }
-    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-    const float b0 = cvalid ? th[0] - hdr->ybar : 0.f;
-    const float t = chain_scale(amax, b0, hdr->ymax, D);
-    float grid, ginv;
-    piece_grid(amax * t, grid, ginv);
-    tc[ct] = t;
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nb0v[ct][i] = -b0 * t;
+    for (int off = 1; off < 16; off <<= 1) {
+      tlo = fminf(tlo, __shfl_xor(tlo, off, 64));
+      thi = fmaxf(thi, __shfl_xor(thi, off, 64));
+    }
+    if (lane == 0) { sred[wave] = tlo; sred[NW + wave] = thi; }
+    __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int w = 0; w < NW; ++w) { tlo = fminf(tlo, sred[w]); thi = fmaxf(thi, sred[NW + w]); }
+    T = tlo < INFINITY ? tlo : 1.f;
+    uni = !(thi > T * 256.f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w1[ct][ks][j] = first_piece(v[ks][j] * t, grid, ginv);
+    for (int ct = 0; ct < CT; ++ct) {
+      const float t = uni ? T : chain_scale(amaxc[ct], b0c[ct], hdr->ymax, D);
+      float grid, ginv;
+      piece_grid(amaxc[ct] * t, grid, ginv);
+      tc[ct] = t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nb0v[ct][i] = -b0c[ct] * t;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w1[ct][ks][j] = first_piece(v[ct][ks][j] * t, grid, ginv);
+    }
   }
+  // tells the finalize kernel which of the two this block did (slot behind the partials)
+  if (rbi == 0 && tid == 0) partials[(int64_t)nrb * C * (dr + 2) + cbi] = uni ? T : 0.f;
 
   f32x4v G[CT][FT];
 #pragma unroll
@@ -505,7 +569,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   float yp;
   bool yvalid;
   const float ybar = hdr->ybar;
-  const float ypad = pad_target(theta, cbi * (16 * CT * NW), dr, ybar);
+  // one scale per block: the staged targets are T (y - ybar), padding rows exact zeros
+  const float ypad = uni ? 0.f : pad_target(theta, hdr->shift, cbi * (16 * CT * NW), dr, ybar);
+  const float ymul = uni ? T : 1.f;
   auto gload = [&](int64_t k) {      // k-th tile of this row block; past the end: tile 0 of the dataset, never used
     const int64_t tile = rbi + k * nrb;
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
@@ -527,7 +593,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if (NCH % NT == 0 || idx < NCH)
         *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
     }
-    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid ? yp - ybar : ypad;
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid ? (yp - ybar) * ymul : ypad;
   };
 
   // ---- per-lane LDS offsets of the three kinds of fragment inside a tile image (unit 0) ----
@@ -559,6 +625,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + (32 * unit + 16 * half) * SA + offX[ft]));
   };
 
+  // UNI: the staged targets are the accumulator the residual product starts from (read a block earlier, no fma);
+  // otherwise it starts from -t b0 and the targets are added by one fma per residual
+  auto pass = [&](auto uni_c) {
+  constexpr bool UNI = decltype(uni_c)::value;
   if (nt > 0) {
     // prologue: tiles 0 and 1 into the ring; P of unit 0; fragments of what block 0 consumes
     gload(0); lstore(0);
@@ -569,15 +639,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         f16x8 a0[KS];
+        YV[0][rt] = read_y(img, 0, rt);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a0[ks] = read_a(img, 0, rt, ks);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
-            Z[0][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], w1[ct][ks], ks == 0 ? nb0v[ct] : Z[0][rt][ct],
-                                                                  0, 0, 0);
-        YV[0][rt] = read_y(img, 0, rt);
+            Z[0][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                a0[ks], w1[ct][ks], ks == 0 ? (UNI ? YV[0][rt] : nb0v[ct]) : Z[0][rt][ct], 0, 0, 0);
+        if constexpr (UNI) YV[1][rt] = read_y(img, 1, rt);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) A[1][rt][ks] = read_a(img, 1, rt, ks);
       }
@@ -602,9 +673,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr int j = decltype(jc)::value;
         constexpr int sq = j & 1, sr = (j + 1) & 1;      // sets: Q / loads of XH, A  |  R, P, loads of YV
         // unit whose A fragments are read (for the P of the next block) and whose y is read (for its Q)
-        constexpr int ua = (j + 2) % UPT, uy = (j + 1) % UPT;
+        // (UNI: y a block earlier, it is an operand of the next block's P)
+        constexpr int ua = (j + 2) % UPT, uy = (j + (UNI ? 2 : 1)) % UPT;
         const unsigned char* ia = j + 2 < UPT ? icur : inxt;
-        const unsigned char* iy = j + 1 < UPT ? icur : inxt;
+        const unsigned char* iy = j + (UNI ? 2 : 1) < UPT ? icur : inxt;
         static_for<NS>([&](auto sc_) {
           constexpr int s = decltype(sc_)::value;
           constexpr int grp = s / 3, r = s % 3;
@@ -620,13 +692,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
           }
           if constexpr (s == 3 || s == 9) {
             constexpr int rt = s == 3 ? 0 : 1;
-            YV[sr][rt] = read_y(iy, uy, rt);
+            YV[UNI ? sq : sr][rt] = read_y(iy, uy, rt);
           }
           // -- the slot's MFMA
           if constexpr (r == 2) {                          // P(j+1): row tile rt, k-step ks, chain tile ct
             constexpr int rt = grp / (CT * KS), ks = (grp / CT) % KS, ct = grp % CT;
-            Z[sr][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[sr][rt][ks], w1[ct][ks],
-                                                                   ks == 0 ? nb0v[ct] : Z[sr][rt][ct], 0, 0, 0);
+            Z[sr][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                A[sr][rt][ks], w1[ct][ks], ks == 0 ? (UNI ? YV[sr][rt] : nb0v[ct]) : Z[sr][rt][ct], 0, 0, 0);
           } else {                                         // R(j-1): feature tile ft, piece, chain tile ct
             constexpr int q = 2 * grp + r, ft = q / (2 * CT), piece = (q % (2 * CT)) / CT, ct = q % CT;
             const f16x8 rv = piece == 0
@@ -644,8 +716,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // balanced over the group's three MFMA gaps by issue cost (the mixed-precision fma costs ~2.6 plain ones):
             // [+ t y, + t y, convert]  [square, low piece of the first]  [square, low piece of the second]
             if constexpr (r == 0) {
-              Z[sq][rt][ct][i0] = fmaf(YV[sq][rt][i0], tc[ct], Z[sq][rt][ct][i0]);
-              Z[sq][rt][ct][i0 + 1] = fmaf(YV[sq][rt][i0 + 1], tc[ct], Z[sq][rt][ct][i0 + 1]);
+              if constexpr (!UNI) {
+                Z[sq][rt][ct][i0] = fmaf(YV[sq][rt][i0], tc[ct], Z[sq][rt][ct][i0]);
+                Z[sq][rt][ct][i0 + 1] = fmaf(YV[sq][rt][i0 + 1], tc[ct], Z[sq][rt][ct][i0 + 1]);
+              }
               const float q0 = Z[sq][rt][ct][i0], q1 = Z[sq][rt][ct][i0 + 1];
               unsigned hi;
               asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(q0), "v"(q1));
@@ -691,6 +765,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if constexpr (GRAD) G[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl, xv, G[ct][ft], 0, 0, 0);
       }
   }
+  };
+  if (uni) pass(std::true_type{});
+  else pass(std::false_type{});
 
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -714,20 +791,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---- pack: column statistics (two-stage, fixed order) then the split ----
-// stage 1: block b reduces rows b, b + nblk, ... : per column abs-max and sum (double), sum and abs-max of y
+// stage 1: block b reduces rows b, b + nblk, ... : per column abs-max and sum (double), sum and abs-max of y.
+// Run twice: first on the columns as they are (shift == nullptr: the sums give the column means), then on the
+// centred columns x - shift (abs-max for the column scales; the sum of the exact differences).
 template <int D>
 __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n, int dr,
-                                    float* __restrict__ pmax, double* __restrict__ psum) {
+                                    const float* __restrict__ shift, float* __restrict__ pmax,
+                                    double* __restrict__ psum) {
   // 256 threads = 256 / D row lanes x D columns
   constexpr int RL = 256 / D;
   const int col = threadIdx.x % D, rl = threadIdx.x / D;
+  const double m = (shift && col < dr) ? (double)shift[col] : 0.0;
   float amax = 0.f;
   float yhi = -INFINITY, ylo = INFINITY;      // largest and smallest y (NaN: kept out by fmaxf / fminf, found by ysum)
   double sum = 0.0, ysum = 0.0;
   for (int64_t row = (int64_t)blockIdx.x * RL + rl; row < n; row += (int64_t)gridDim.x * RL) {
-    const float v = col < dr ? X[row * dr + col] : 0.f;
-    amax = fmaxf(amax, fabsf(v));
-    sum += (double)v;
+    const double v = col < dr ? (double)X[row * dr + col] - m : 0.0;
+    amax = fmaxf(amax, fabsf((float)v));
+    sum += v;
     if (col == 0) {
       ysum += (double)y[row];
       yhi = fmaxf(yhi, y[row]);
@@ -762,7 +843,9 @@ __global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __
   }
 }
 
-template <int D>
+// CENTRED = false (after the first statistics pass): the shift vector (column means in f32, 0 where not finite) and
+// the statistics of y; CENTRED = true (after the second): the scales and sums of the centred columns
+template <int D, bool CENTRED>
 __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* __restrict__ psum, int nblk,
                                     int64_t n, Header* __restrict__ hdr) {
   const int col = threadIdx.x;
@@ -773,13 +856,22 @@ __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* 
       amax = fmaxf(amax, pmax[(int64_t)b * (D + 2) + col]);
       sum += psum[(int64_t)b * (D + 1) + col];
     }
-    hdr->colscale[col] = amax > 0.f ? col_scale(amax) : 0.f;   // 0 marks an all-zero column
-    hdr->colsum[col] = sum;
+    if (CENTRED) {
+      hdr->colscale[col] = amax > 0.f ? col_scale(amax) : 0.f;   // 0 marks an all-zero (here: constant) column
+      hdr->colsum[col] = sum;
+    } else {
+      const float mean = n > 0 ? (float)(sum / (double)n) : 0.f;
+      hdr->shift[col] = isfinite(mean) ? mean : 0.f;
+    }
   } else if (col < 64) {
-    hdr->colscale[col] = 0.f;
-    hdr->colsum[col] = 0.0;
+    if (CENTRED) {
+      hdr->colscale[col] = 0.f;
+      hdr->colsum[col] = 0.0;
+    } else {
+      hdr->shift[col] = 0.f;
+    }
   }
-  if (col == 0) {
+  if (col == 0 && !CENTRED) {
     double ys = 0.0;
     float yhi = -INFINITY, ylo = INFINITY;
     for (int b = 0; b < nblk; ++b) {
@@ -822,20 +914,21 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
     }
     f16x8 fh;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) fh[j] = (_Float16)(v[j] * hdr->colscale[scol + j]);
+    for (int j = 0; j < 8; ++j)      // padding rows stay zero (not -shift)
+      fh[j] = ok ? (_Float16)plane_value(v[j], hdr->shift[scol + j], hdr->colscale[scol + j]) : (_Float16)0.f;
     *reinterpret_cast<f16x8*>(planes + (row * D + scol) * 2) = fh;
     if (scol == 0) *reinterpret_cast<float*>(yplane + row * 4) = ok ? y[row] : 0.f;
   }
 }
 
-// X^T X in double, stage 1: block b takes the 64-row tiles b, b + nblk, ...; a thread owns an E x E block of
+// X^T X (of the centred columns) in double, stage 1: block b takes the 64-row tiles b, b + nblk, ...; a thread owns an E x E block of
 // the matrix (E = D / 16).  Partials [nblk][64][64]; only the D x D corner is written.
 constexpr int kGramBlocks = 256;
 template <int D>
 __global__ __launch_bounds__(256) void f16_gram_kernel(const float* __restrict__ X, int64_t n, int dr,
-                                                       double* __restrict__ gpart) {
+                                                       const Header* __restrict__ hdr, double* __restrict__ gpart) {
   constexpr int E = D / 16;
-  __shared__ float xt[64][D + 1];
+  __shared__ double xt[64][D + 1];       // the centred rows x - shift, exact
   const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
   double acc[E][E];
 #pragma unroll
@@ -848,15 +941,15 @@ __global__ __launch_bounds__(256) void f16_gram_kernel(const float* __restrict__
     for (int e = threadIdx.x; e < 64 * D; e += 256) {
       const int r = e / D, col = e - r * D;
       const int64_t row = t * 64 + r;
-      xt[r][col] = (row < n && col < dr) ? X[row * dr + col] : 0.f;
+      xt[r][col] = (row < n && col < dr) ? (double)X[row * dr + col] - (double)hdr->shift[col] : 0.0;
     }
     __syncthreads();
     for (int r = 0; r < 64; ++r) {
       double xa[E], xb[E];
 #pragma unroll
       for (int i = 0; i < E; ++i) {
-        xa[i] = (double)xt[r][E * a + i];
-        xb[i] = (double)xt[r][E * b + i];
+        xa[i] = xt[r][E * a + i];
+        xb[i] = xt[r][E * b + i];
       }
 #pragma unroll
       for (int i = 0; i < E; ++i)
@@ -880,7 +973,7 @@ __global__ void f16_gram_final(const double* __restrict__ gpart, int nblk, int D
   gram[e] = s;
 }
 
-// What the f16 plane leaves of X, xr = x - xh (exact in f32), enters every sum linearly, so its effect is known
+// What the f16 plane leaves of the centred X, xr = (x - shift) - xh (in double), enters every sum linearly, so its effect is known
 // in closed form from four pack-time sums in double (see the top of this file):
 //   A  = X^T X - XH^T XH, accumulated term by term as xh_f xr_g + xr_f x_g (no cancellation), symmetric
 //   Bt[g][f] = sum_i xr_if xh_ig,   XR^T y,   XR^T 1.
@@ -891,7 +984,8 @@ __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ 
                                                       int64_t n, int dr, const Header* __restrict__ hdr,
                                                       double* __restrict__ lpart) {
   constexpr int E = D / 16;
-  __shared__ float xt[64][D + 1], ht[64][D + 1], yt[64];
+  __shared__ double xt[64][D + 1];       // centred and scaled entries, exact
+  __shared__ float ht[64][D + 1], yt[64];
   const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
   double accA[E][E], accB[E][E], vy[E], v1[E];
 #pragma unroll
@@ -910,10 +1004,12 @@ __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ 
     for (int e = threadIdx.x; e < 64 * D; e += 256) {
       const int r = e / D, col = e - r * D;
       const int64_t row = t * 64 + r;
-      const float v = (row < n && col < dr) ? X[row * dr + col] : 0.f;
-      const float q = v * hdr->colscale[col];          // the pack kernel's rounding, in the column's scale
-      xt[r][col] = q;
-      ht[r][col] = (float)(_Float16)q;
+      const bool in = row < n && col < dr;
+      const float v = in ? X[row * dr + col] : 0.f;
+      // the pack kernel's rounding, in the column's scale; xt keeps the exact centred value (the float rounding of
+      // x - shift is part of what the plane leaves out)
+      xt[r][col] = in ? ((double)v - (double)hdr->shift[col]) * (double)hdr->colscale[col] : 0.0;
+      ht[r][col] = in ? (float)(_Float16)plane_value(v, hdr->shift[col], hdr->colscale[col]) : 0.f;
     }
     if (threadIdx.x < 64) yt[threadIdx.x] = t * 64 + threadIdx.x < n ? y[t * 64 + threadIdx.x] : 0.f;
     __syncthreads();
@@ -921,10 +1017,10 @@ __global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ 
       double xa[E], ha[E], ra[E], xb[E], hb[E], rb[E];
 #pragma unroll
       for (int i = 0; i < E; ++i) {
-        xa[i] = (double)xt[r][E * a + i];
+        xa[i] = xt[r][E * a + i];
         ha[i] = (double)ht[r][E * a + i];
         ra[i] = xa[i] - ha[i];
-        xb[i] = (double)xt[r][E * b + i];
+        xb[i] = xt[r][E * b + i];
         hb[i] = (double)ht[r][E * b + i];
         rb[i] = xb[i] - hb[i];
       }
@@ -990,11 +1086,16 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
   __shared__ double part[5][kFinGroups][64];
   __shared__ double sums[66], dw[64], wv[64], s2t[64];
-  __shared__ float sh_t;
+  __shared__ float sh_t, sh_b0c;
+  __shared__ double sh_bt, sh_s1;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
   const double* low = reinterpret_cast<const double*>(packed + kLowOffset);
   const float* th = theta + (int64_t)c * q2;
+  // how the streaming kernel scaled this chain's block: > 0 = one scale for the whole block, targets entering
+  // through the accumulator and no intercept at all in the kernel; 0 = one scale and one intercept per chain
+  const float block_scale = partials[(int64_t)nb * tot + c / cpb];
+  const double nn = (double)n;
   if (grp == 0) {
     // dw_f = w_f - (what the kernel's f16 piece of the scaled weight stands for), recomputed with the kernel's
     // own arithmetic: w'' = -w / s_f * t, piece w1, remainder exact in f32
@@ -1003,14 +1104,28 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     float amax = fabsf(v);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-    const float t = chain_scale(amax, th[0] - hdr->ybar, hdr->ymax, dplane);
+    const float b0cen = centred_intercept(th, hdr->shift, d, hdr->ybar);
+    const float t = block_scale > 0.f ? block_scale : chain_scale(amax, b0cen, hdr->ymax, dplane);
     float grid, ginv;
     piece_grid(amax * t, grid, ginv);
     const float q = v * t;
     const float rem = q - (float)first_piece(q, grid, ginv);        // exact: the piece is q rounded to a coarser grid
     dw[o] = cs > 0.f ? -(double)rem * (double)cs / (double)t : 0.0;
     wv[o] = o < d ? (double)th[1 + o] : 0.0;
-    if (o == 0) sh_t = t;
+    // the exact intercept in the centred frame, b0 + shift . w, and S1 = sum_i r_i from the packed sums
+    double mw = o < d ? (double)hdr->shift[o] * (double)th[1 + o] : 0.0;
+    double wc = o < d ? (double)th[1 + o] * hdr->colsum[o] : 0.0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      mw += __shfl_xor(mw, off, 64);
+      wc += __shfl_xor(wc, off, 64);
+    }
+    if (o == 0) {
+      sh_t = t;
+      sh_b0c = block_scale > 0.f ? 0.f : b0cen;      // the intercept (relative to ybar) the kernel worked with
+      sh_bt = (double)th[0] + mw;
+      sh_s1 = hdr->ysum - nn * ((double)th[0] + mw) - wc;
+    }
   }
   for (int q0 = 0; q0 < q2; q0 += 64) {
     const int q = q0 + o;
@@ -1028,12 +1143,14 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     __syncthreads();
   }
   const double u = (double)sh_t;       // the chain's scale: S2' = t^2 S2_k, G'_f = t s_f G_k,f
-  // the kernel's intercept is ybar + fl32(b0 - ybar); what that leaves of b0 is handled like dw, in closed form
-  const float b0c = th[0] - hdr->ybar;
+  // the kernel's intercept is ybar + (the float it worked with: the centred intercept summed in float, or none at
+  // all); what that leaves of the exact centred intercept bt = b0 + shift . w is handled like dw, in closed form
+  const float b0c = sh_b0c;
+  const double bt = sh_bt;
   const double b0_eff = (double)hdr->ybar + (double)b0c;
-  const double db = (double)th[0] - b0_eff;
+  const double db = bt - b0_eff;
   const double sc = (double)th[d + 1];
-  const double inv2 = 1.0 / (sc * sc), nn = (double)n;
+  const double inv2 = 1.0 / (sc * sc);
   {
     // (X^T X dw)_f, (A w)_f, (A dw)_f (both matrices symmetric), (B w)_f, (B dw)_f: a wave takes every
     // kFinGroups-th g
@@ -1067,30 +1184,35 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     // (G'_f = t s_f G_k,f).  The true residual is r = r_k - (db + xr.w + xh.dw), hence
     //   G = G_k - A wk - (X^T X) dw + t1 - db XH^T 1,   t1 = XR^T y - b0 XR^T 1,   XH^T 1 = X^T 1 - XR^T 1
     //   S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B wk + dw . (X^T X - A) dw)
-    //        - 2 db (sum y - n b0_eff - w . XH^T 1) + n db^2,   cr = t1 + db XR^T 1 - B wk = sum xr r_k
+    //        - 2 db (sum y - n b0_eff - w . X^T 1) + n db^2,   cr = t1 + db XR^T 1 - B wk = sum xr r_k
+    // (db: -2 db sum r_k from the cross term, + 2 db (w . XR^T 1 + dw . XH^T 1) from the square of what was left out)
     const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;
     const double xr1 = low[8192 + 64 + f];
     const double sxh = hdr->colsum[f] - xr1;
-    const double t1 = low[8192 + f] - (double)th[0] * xr1;
+    const double t1 = low[8192 + f] - bt * xr1;
     const double bwk = m[3] - m[4];
     s2t[f] = -2.0 * (wv[f] * (t1 + db * xr1 - bwk) + dw[f] * g0) + wv[f] * (m[1] - 2.0 * bwk) + dw[f] * (m[0] - m[2]) +
-             2.0 * db * wv[f] * sxh;
-    if (grad) grad[(int64_t)c * q2 + 1 + f] = (float)((g0 - (m[1] - m[2]) - m[0] + t1 - db * sxh) * inv2);
+             2.0 * db * wv[f] * (sxh + xr1);
+    // (the sums are those of the centred columns: d/dw_f = sum_i (x~_if + shift_f) r_i)
+    if (grad)
+      grad[(int64_t)c * q2 + 1 + f] =
+          (float)((g0 - (m[1] - m[2]) - m[0] + t1 - db * sxh + (double)hdr->shift[f] * sh_s1) * inv2);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     // padding rows of the last tile came through as r' = fma(ypad, t, -t (b0 - ybar)): out again
     const double npad = (double)((n + kTileRows - 1) / kTileRows * kTileRows - n);
-    const float rpad = fmaf(pad_target(theta, (c / cpb) * cpb, d, hdr->ybar), sh_t, -b0c * sh_t);
+    // (with one scale per block the padding rows are exact zeros)
+    const float rpad = block_scale > 0.f
+                           ? 0.f
+                           : fmaf(pad_target(theta, hdr->shift, (c / cpb) * cpb, d, hdr->ybar), sh_t, -b0c * sh_t);
     double s2 = (sums[0] + sums[1] - npad * (double)rpad * (double)rpad) / (u * u);   // S2' arrives as a float pair
     s2 += -2.0 * db * (hdr->ysum - nn * b0_eff) + nn * db * db;
     for (int f = 0; f < d; ++f) s2 += s2t[f];
     logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D - (ref ? *ref : 0.0));
     if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
   } else if (threadIdx.x == 64 && grad) {
-    double s1 = hdr->ysum - nn * (double)th[0];
-    for (int j = 0; j < d; ++j) s1 -= (double)th[1 + j] * hdr->colsum[j];
-    grad[(int64_t)c * q2] = (float)(s1 * inv2);
+    grad[(int64_t)c * q2] = (float)(sh_s1 * inv2);
   }
 }
 
@@ -1132,18 +1254,28 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
   if (dp == 64) {
-    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
-    hipLaunchKernelGGL(f16_header_kernel<64>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
-                       kStatBlocks, n, (Header*)packed);
+    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
+                       pmax, psum);
+    hipLaunchKernelGGL((f16_header_kernel<64, false>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+                       (const double*)psum, kStatBlocks, n, (Header*)packed);
+    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d,
+                       (const float*)((const Header*)packed)->shift, pmax, psum);
+    hipLaunchKernelGGL((f16_header_kernel<64, true>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+                       (const double*)psum, kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
-    hipLaunchKernelGGL(f16_gram_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
+    hipLaunchKernelGGL(f16_gram_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, (const Header*)packed, gpart);
     hipLaunchKernelGGL(f16_low_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
   } else {
-    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
-    hipLaunchKernelGGL(f16_header_kernel<32>, dim3(1), dim3(64), 0, s, (const float*)pmax, (const double*)psum,
-                       kStatBlocks, n, (Header*)packed);
+    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
+                       pmax, psum);
+    hipLaunchKernelGGL((f16_header_kernel<32, false>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+                       (const double*)psum, kStatBlocks, n, (Header*)packed);
+    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d,
+                       (const float*)((const Header*)packed)->shift, pmax, psum);
+    hipLaunchKernelGGL((f16_header_kernel<32, true>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+                       (const double*)psum, kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
-    hipLaunchKernelGGL(f16_gram_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, gpart);
+    hipLaunchKernelGGL(f16_gram_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, (const Header*)packed, gpart);
     hipLaunchKernelGGL(f16_low_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
   }
   hipLaunchKernelGGL(f16_gram_final, dim3(16), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp, gram);

@@ -279,6 +279,55 @@ def test_linreg_f16_pieces_column_ranges(nat, ws, gpu_device):
     assert (err <= 1e-5 * np.abs(ref_g) + 3e-7 * ts + 1e-30).all(), float((err / (np.abs(ref_g) + ts * 3e-2)).max())
 
 
+@pytest.mark.parametrize('c', [256, 130])
+def test_linreg_f16_block_scale_and_per_chain_scale_agree(nat, ws, gpu_device, c):
+    """Many-chain blocks whose chains have natural scales within 2^8 of each other work with one scale and no
+    intercept in the streaming pass (targets enter through the accumulator, the intercept in closed form); a block
+    with one chain a thousand times further out keeps one scale and one intercept per chain.  The other chains
+    must come out the same either way, and both ways within the bar of the float64 closed form."""
+    rng = np.random.default_rng(41)
+    n, d = 30000, 64
+    X, y, th = _linreg_case(rng, n, d, c, spread=0.02)
+    far = th.copy()
+    far[7, 1:1 + d] *= 1000.0            # scale 2^10 below the others': the block takes the per-chain route
+    ref_lp, ref_g = cf.linreg(X, y, far)
+    lp_u, g_u = _f16_eval(nat, ws, gpu_device, X, y, th)
+    lp_f, g_f = _f16_eval(nat, ws, gpu_device, X, y, far)
+    assert_logp_close(lp_f, ref_lp)
+    assert_grad_close(g_f, ref_g, term_scale=_linreg_term_scale(X, y, far))
+    near = np.ones(c, bool); near[7] = False
+    assert (np.abs(lp_u[near] - lp_f[near]) <= 2e-6 * np.abs(lp_f[near])).all()
+    assert_logp_close(lp_u[near], ref_lp[near])
+    assert (np.abs(g_u[near] - g_f[near]).max(-1) <= 1e-5 * np.abs(ref_g[near]).max(-1)).all()
+    ref_lp_u, ref_g_u = cf.linreg(X, y, th)
+    assert_logp_close(lp_u, ref_lp_u)
+    assert_grad_close(g_u, ref_g_u, term_scale=_linreg_term_scale(X, y, th))
+
+
+@pytest.mark.parametrize('c', [4, 160])
+def test_linreg_f16_columns_far_off_centre(nat, ws, gpu_device, c):
+    """Columns whose mean is 30 - 1000 times their spread, chains near the mode and chains scattered around it:
+    the packed plane holds the centred columns and the kernels work with the intercept at the centroid, so
+    neither the f16 range nor the closed-form intercept loses anything to the offsets."""
+    rng = np.random.default_rng(77)
+    n, d = 60000, 64
+    offs = rng.choice([-1.0, 1.0], d) * 10.0 ** rng.uniform(1.5, 3.0, d)
+    X = (rng.normal(size=(n, d)) + offs).astype(np.float32)
+    w = rng.normal(size=d)
+    y = (2.0 + X.astype(np.float64) @ w + rng.normal(size=n)).astype(np.float32)
+    A = np.concatenate([np.ones((n, 1)), X.astype(np.float64)], 1)
+    ols = np.linalg.lstsq(A, y.astype(np.float64), rcond=None)[0]
+    width = np.where(np.arange(c) % 2 == 0, 1.0 / math.sqrt(n), 0.05)[:, None]
+    # scattered chains keep their fit at the centroid: the intercept follows the weights
+    dw = width * rng.normal(size=(c, d))
+    b0 = ols[0] - dw @ X.astype(np.float64).mean(0) + width[:, 0] * rng.normal(size=c)
+    th = np.concatenate([b0[:, None], ols[None, 1:] + dw, rng.uniform(0.9, 1.2, (c, 1))], -1).astype(np.float32)
+    ref_lp, ref_g = cf.linreg(X, y, th)
+    lp, g = _f16_eval(nat, ws, gpu_device, X, y, th)
+    assert_logp_close(lp, ref_lp)
+    assert_grad_close(g, ref_g, term_scale=_linreg_term_scale(X, y, th))
+
+
 def test_linreg_f16_pieces_edge_behaviour(nat, ws, gpu_device):
     rng = np.random.default_rng(3)
     X, y, th = _linreg_case(rng, 5000, 64, 130)
