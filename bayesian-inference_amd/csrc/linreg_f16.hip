@@ -119,13 +119,40 @@ __device__ __forceinline__ float chain_scale(float amax_v, float b0, float ymax,
 // The columns are centred at pack time (x~ = x - shift, shift = the column means in f32), so the model reads
 //   y - b0 - x . w = (y - ybar) - (b0 - ybar + shift . w) - x~ . w:
 // the intercept the kernels and the finalize kernel work with is the chain's fitted value at the centroid of the
-// data relative to ybar.  Summed in this fixed order wherever it is needed (the finalize kernel has to reproduce the
-// kernels' float bit for bit; what the float leaves of the exact value is carried in closed form there).
-__device__ __forceinline__ float centred_intercept(const float* __restrict__ th, const float* __restrict__ shift,
-                                                   int dr, float ybar) {
-  float acc = th[0] - ybar;
-  for (int f = 0; f < dr; ++f) acc = fmaf(shift[f], th[1 + f], acc);
-  return acc;
+// data relative to ybar.  The finalize kernel has to reproduce the kernels' float bit for bit (what the float leaves
+// of the exact value is carried in closed form there), so the sum has ONE order everywhere: the 64 products
+// shift_f w_f (0 beyond the model's features), added as a butterfly over the feature index (f ^ 32, 16, ..., 1),
+// then (b0 - ybar) + sum, every operation rounded on its own (no contraction).
+// Here: for a lane of the matrix kernels, which holds features 32 ks + 8 g + j of its chain (g = lane >> 4).
+template <int KS>
+__device__ __forceinline__ float centred_intercept_frag(const float* __restrict__ th,
+                                                        const float* __restrict__ shift, int dr, int g, float ybar) {
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int f0 = 8 * g + j, f1 = 32 + 8 * g + j;
+    const float p0 = f0 < dr ? __fmul_rn(shift[f0], th[1 + f0]) : 0.f;
+    const float p1 = (KS == 2 && f1 < dr) ? __fmul_rn(shift[f1], th[1 + f1]) : 0.f;
+    a[j] = __fadd_rn(p0, p1);                                   // f ^ 32
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = __fadd_rn(a[j], __shfl_xor(a[j], 32, 64));   // f ^ 16
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = __fadd_rn(a[j], __shfl_xor(a[j], 16, 64));   // f ^ 8
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = __fadd_rn(a[j], a[j + 4]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) a[j] = __fadd_rn(a[j], a[j + 2]);
+  return __fadd_rn(th[0] - ybar, __fadd_rn(a[0], a[1]));
+}
+
+// The same sum by a whole wave whose lane o holds feature o (the finalize kernel)
+__device__ __forceinline__ float centred_intercept_wave(const float* __restrict__ th,
+                                                        const float* __restrict__ shift, int d, int o, float ybar) {
+  float p = o < d ? __fmul_rn(shift[o], th[1 + o]) : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) p = __fadd_rn(p, __shfl_xor(p, off, 64));
+  return __fadd_rn(th[0] - ybar, p);
 }
 
 // Scaled entry of the centred plane before its rounding to f16: the exact difference x - shift, times the column's
@@ -136,10 +163,8 @@ __device__ __forceinline__ float plane_value(float x, float shift, float colscal
 
 // Target value given to the padding rows of the last tile: the centred intercept of the first chain of the
 // workgroup's chain block (0 if that is not finite)
-__device__ __forceinline__ float pad_target(const float* __restrict__ theta, const float* __restrict__ shift,
-                                            int first_chain, int dr, float ybar) {
-  const float v = centred_intercept(theta + (int64_t)first_chain * (dr + 2), shift, dr, ybar);
-  return isfinite(v) ? v : 0.f;
+__device__ __forceinline__ float pad_value(float first_chain_intercept) {
+  return isfinite(first_chain_intercept) ? first_chain_intercept : 0.f;
 }
 
 // Grid of the first f16 piece of a chain's scaled weights: 2^-13 of the binade of the largest one (as a pair:
@@ -226,7 +251,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));   // the four lane groups hold the chain's D features
       amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
       // the intercept against the centred targets and columns
-      const float b0 = cvalid ? centred_intercept(th, hdr->shift, dr, hdr->ybar) : 0.f;
+      const float b0i = centred_intercept_frag<KS>(th, hdr->shift, dr, g, hdr->ybar);
+      const float b0 = cvalid ? b0i : 0.f;
       const float t = chain_scale(amax, b0, hdr->ymax, D);
       float grid, ginv;
       piece_grid(amax * t, grid, ginv);
@@ -262,7 +288,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   float yp;
   bool yvalid;
   const float ybar = hdr->ybar;
-  const float ypad = pad_target(theta, hdr->shift, cbi * (16 * CT * NW), dr, ybar);
+  const float ypad = pad_value(centred_intercept_frag<KS>(theta + (int64_t)cbi * (16 * CT * NW) * (dr + 2), hdr->shift, dr, g, ybar));
   auto gload = [&](int64_t tile) {
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
 #pragma unroll
@@ -512,7 +538,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
       amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
       amaxc[ct] = amax;
-      b0c[ct] = cvalid ? centred_intercept(th, hdr->shift, dr, hdr->ybar) : 0.f;
+      const float b0i = centred_intercept_frag<KS>(th, hdr->shift, dr, g, hdr->ybar);
+      b0c[ct] = cvalid ? b0i : 0.f;
       // the chain's scale without an intercept; chains whose bound is not finite (they return NaN whatever the
       // scale) and lanes beyond the last chain take no part in the block's choice
       const float bound = hdr->ymax + (float)D * (float)(2 << kColTop) * amax;
@@ -570,7 +597,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   bool yvalid;
   const float ybar = hdr->ybar;
   // one scale per block: the staged targets are T (y - ybar), padding rows exact zeros
-  const float ypad = uni ? 0.f : pad_target(theta, hdr->shift, cbi * (16 * CT * NW), dr, ybar);
+  const float ypad = uni ? 0.f : pad_value(centred_intercept_frag<KS>(theta + (int64_t)cbi * (16 * CT * NW) * (dr + 2), hdr->shift, dr, g, ybar));
   const float ymul = uni ? T : 1.f;
   auto gload = [&](int64_t k) {      // k-th tile of this row block; past the end: tile 0 of the dataset, never used
     const int64_t tile = rbi + k * nrb;
@@ -724,11 +751,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
               unsigned hi;
               asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(q0), "v"(q1));
               RH[sq][ct][jp] = hi;
+              if constexpr (UNI) a2[ct] = fmaf(q0, q0, a2[ct]);     // (no target fma here: the squares move up a gap)
             } else if constexpr (r == 1) {
               const float q0 = Z[sq][rt][ct][i0];
               const unsigned hi = RH[sq][ct][jp];
               unsigned lo;
-              a2[ct] = fmaf(q0, q0, a2[ct]);
+              if constexpr (UNI) {
+                const float q1 = Z[sq][rt][ct][i0 + 1];
+                a2[ct] = fmaf(q1, q1, a2[ct]);
+              } else {
+                a2[ct] = fmaf(q0, q0, a2[ct]);
+              }
               if constexpr (GRAD) {
                 asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(q0), "v"(hi));
                 RL[sq][ct][jp] = lo;
@@ -737,7 +770,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
               const float q1 = Z[sq][rt][ct][i0 + 1];
               const unsigned hi = RH[sq][ct][jp];
               unsigned lo = RL[sq][ct][jp];
-              a2[ct] = fmaf(q1, q1, a2[ct]);
+              if constexpr (!UNI) a2[ct] = fmaf(q1, q1, a2[ct]);
               if constexpr (GRAD) {
                 asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(q1), "v"(hi));
                 RL[sq][ct][jp] = lo;
@@ -1086,7 +1119,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
   __shared__ double part[5][kFinGroups][64];
   __shared__ double sums[66], dw[64], wv[64], s2t[64];
-  __shared__ float sh_t, sh_b0c;
+  __shared__ float sh_t, sh_b0c, sh_pad;
   __shared__ double sh_bt, sh_s1;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const double* gram = reinterpret_cast<const double*>(packed + kGramOffset);
@@ -1104,7 +1137,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     float amax = fabsf(v);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-    const float b0cen = centred_intercept(th, hdr->shift, d, hdr->ybar);
+    const float b0cen = centred_intercept_wave(th, hdr->shift, d, o, hdr->ybar);
     const float t = block_scale > 0.f ? block_scale : chain_scale(amax, b0cen, hdr->ymax, dplane);
     float grid, ginv;
     piece_grid(amax * t, grid, ginv);
@@ -1120,8 +1153,10 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
       mw += __shfl_xor(mw, off, 64);
       wc += __shfl_xor(wc, off, 64);
     }
+    const float padv = pad_value(centred_intercept_wave(theta + (int64_t)(c / cpb) * cpb * q2, hdr->shift, d, o, hdr->ybar));
     if (o == 0) {
       sh_t = t;
+      sh_pad = padv;
       sh_b0c = block_scale > 0.f ? 0.f : b0cen;      // the intercept (relative to ybar) the kernel worked with
       sh_bt = (double)th[0] + mw;
       sh_s1 = hdr->ysum - nn * ((double)th[0] + mw) - wc;
@@ -1205,7 +1240,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     // (with one scale per block the padding rows are exact zeros)
     const float rpad = block_scale > 0.f
                            ? 0.f
-                           : fmaf(pad_target(theta, hdr->shift, (c / cpb) * cpb, d, hdr->ybar), sh_t, -b0c * sh_t);
+                           : fmaf(sh_pad, sh_t, -b0c * sh_t);
     double s2 = (sums[0] + sums[1] - npad * (double)rpad * (double)rpad) / (u * u);   // S2' arrives as a float pair
     s2 += -2.0 * db * (hdr->ysum - nn * b0_eff) + nn * db * db;
     for (int f = 0; f < d; ++f) s2 += s2t[f];
