@@ -39,8 +39,20 @@
 // of two), which recomputes t_c with the same arithmetic.  S1 = sum_i r_i is not accumulated at all: it equals
 // sum y - n b0 - w . (column sums of X), with the data sums taken once, in double, at pack time.
 //
+// The columns are centred at pack time: everything below that says x or X means x~ = x - shift with shift the
+// column means rounded to f32 (the differences are exact in double; what their rounding to f32 loses is part of xr),
+// and b0 means the intercept at the centroid, b0 + shift . w.  That intercept is orthogonal to every sum over the
+// rows (sum x~ ~ 0, sum (y - ybar) ~ 0: S2 = S2_k + n db^2 up to the plane's remainders, nothing cancels), so for
+// many chains it need not enter the streaming pass at all: a block of 256 chains whose natural scales lie within
+// 2^8 of each other works with ONE scale T and NO intercept -- the staged targets T (y - ybar) are then the same
+// numbers for every chain and are simply the accumulator the residual product starts from (no vector instruction
+// per residual) -- and the finalize kernel adds the whole intercept in closed form, as it adds the remainders of W
+// (db below is then b0 itself instead of a rounding remainder).  3.3 -> 3.1 - 3.2 ms at the headline shape.
+// A block whose chains lie further apart (one on its way to infinity next to settled ones) keeps one scale and one
+// intercept per chain and one fma per residual, as the few-chain kernel does.
+//
 // Packed dataset (bvi_linreg_pack, format BVI_PACK_F16), 16-B aligned throughout:
-//   header [1024 B]: float colscale[64]; double colsum[64]; double ysum; float ymax
+//   header [1280 B]: float colscale[64]; double colsum[64] (of x~); double ysum; float ymax, ybar; float shift[64]
 //   gram   [64][64] double: X^T X (rows / columns beyond the model's features are zero)
 //   low    [64][64] double A, [64][64] double Bt (Bt[g][f] = B_fg), double[64] XR^T y, double[64] XR^T 1
 //   plane  [n_pad][D] f16: x'                          (D = 32 or 64 >= the model's feature count; padding
@@ -702,6 +714,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // unit whose A fragments are read (for the P of the next block) and whose y is read (for its Q)
         // (UNI: y a block earlier, it is an operand of the next block's P)
         constexpr int ua = (j + 2) % UPT, uy = (j + (UNI ? 2 : 1)) % UPT;
+        // The two waves of a SIMD (w and w + NW / 2) run the same stream; left alone the older one wins every issue
+        // slot, reaches the tile's barrier early and waits there while the other finishes on its own.  Handing the
+        // priority over in the middle of the tile lets the second one catch up before the barrier (measured 1.3 - 2 %;
+        // other hand-over points gained less or lost, a late one -- three units to one -- 17 %).
+        if constexpr (j == 0) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        if constexpr (j == UPT / 2) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
         const unsigned char* ia = j + 2 < UPT ? icur : inxt;
         const unsigned char* iy = j + (UNI ? 2 : 1) < UPT ? icur : inxt;
         static_for<NS>([&](auto sc_) {

@@ -140,7 +140,7 @@ int bvi_normal_iid_logp_grad_noalloc(const float* y, int64_t n, const float* the
  * This entry point reads the caller's f32 matrix as it is and keeps nothing between calls.  A caller that
  * evaluates the same dataset many times (every sampler does) should pack it once with
  * bvi_linreg_pack(BVI_PACK_F16) and call bvi_linreg_packed_logp_grad: at n = 10M, d = 64, 1024 chains that is
- * 3.5 ms per evaluation against 8.2 ms here, and half the HBM traffic at few chains. */
+ * 3.1 - 3.3 ms per evaluation against 8.2 ms here, and half the HBM traffic at few chains. */
 int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta,
                          int n_chains, int precision, float* logp, float* grad, const double* logp_ref,
                          void* ws, size_t ws_bytes, void* stream);
@@ -152,16 +152,20 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
  * copies.  Formats:
  *   BVI_PACK_BF16X3  d = 32 or 64; three bf16 piece planes [3][n_pad][d] + a 16-B row extension;
  *                    evaluated with precision BF16X6 (default) or BF16X3;
- *   BVI_PACK_F16     1 <= d <= 64; per-column power-of-two scales, data sums and max|y| in a 1024-B
- *                    header, then [64][64] doubles X^T X, A = X^T X - XH^T XH and XR^T XH (transposed), and
- *                    64 doubles each XR^T y and XR^T 1 (XH: the f16 plane, XR = X - XH, exact), then one f16
- *                    plane [n_pad][32 or 64] of the scaled X, zero beyond column d, + y[n_pad] in f32;
+ *   BVI_PACK_F16     1 <= d <= 64; the columns are centred (x~ = x - shift, shift = the column means in f32;
+ *                    the model's intercept becomes the fitted value at the centroid, b0 + shift . w, which is
+ *                    orthogonal to every sum over the rows); a 1280-B header with per-column power-of-two scales
+ *                    of x~, the shifts, data sums and max|y - mean y|, then [64][64] doubles X^T X,
+ *                    A = X^T X - XH^T XH and XR^T XH (transposed), and 64 doubles each XR^T y and XR^T 1 (X: the
+ *                    centred matrix, XH: its f16 plane, XR = X - XH, exact), then one f16 plane
+ *                    [n_pad][32 or 64] of the scaled x~, zero beyond column d, + y[n_pad] in f32;
  *                    n_pad = n rounded up to 128; precision must be AUTO.  Both contractions over the rows run
  *                    on the f16 matrix cores (f16 plane times one f16 piece of the weights; residuals in 2
- *                    pieces times the f16 plane); what the f16 operands leave of X and of the weights enters
- *                    every sum linearly and is added exactly, in double, from those pack-time sums after the
- *                    reduction.  Log-density at f32 accuracy, gradient error at the level of the exact-f32
- *                    kernel's, for residuals down to ~1/5000 of the fitted values.
+ *                    pieces times the f16 plane); what the f16 operands leave of X and of the weights, and
+ *                    (for many chains) the intercept, enter every sum linearly and are added exactly, in
+ *                    double, from those pack-time sums after the reduction.  Log-density at f32 accuracy,
+ *                    gradient error at the level of the exact-f32 kernel's, for residuals down to ~1/5000 of
+ *                    the fitted values and columns whose mean is up to ~1000 times their spread.
  * Padding rows are zero (BF16X3: n_pad = n rounded up to 64).  bvi_linreg_pack needs bvi_linreg_pack_scratch_bytes
  * of workspace (0 for BF16X3). */
 #define BVI_PACK_BF16X3 0
