@@ -266,7 +266,7 @@ def main():
     alg_bytes = 4.0 * n_local * (d + 1) + 8.0 * c * (d + 2)
     fmt = lik.matrix_core_format(c)
     uses_mfma16 = fmt is not None
-    kernel_name = {None: 'linreg_f32_kernel', _native.PACK_F16: 'linreg_f16_pipe_kernel<64, 8>',
+    kernel_name = {None: 'linreg_f32_kernel', _native.PACK_F16: 'linreg_f16_pipe_kernel<64, 8, true>',
                    _native.PACK_BF16X3: 'linreg_bf16x3_kernel<64, %d, true>' % (2 if prec == _native.PREC_BF16X3 else 3)}[fmt]
     peak = MFMA_BF16_PEAK_TFLOPS if uses_mfma16 else MFMA_F32_PEAK_TFLOPS
     achieved = flops / (kern_ms * 1e-3) / 1e12
