@@ -573,6 +573,15 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       for (int j = 0; j < NG; ++j) {
         const int rt = j / KQ, q = j % KQ;
         const int jn = j + 1, rtn = jn / KQ, qn = jn % KQ;
+        // The two waves of a SIMD (w and w + FW / 2) run the same stream between the same barriers; left alone the
+        // older one wins every issue slot, reaches the barrier early and waits while the other finishes on its
+        // own.  Handing the priority over in the middle of a phase lets the second one catch up: here waves 0 - 3
+        // first, in the raw-sums phase below waves 4 - 7 first (13.6 -> 13.0 ms; this phase alone 13.35, the other
+        // orders of the raw-sums phase slower than none).
+        if (GRAD) {
+          if (j == 0) { if (wave < FW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+          if (j == NG / 2) { if (wave < FW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        }
         if (jn < NG && qn == 0) load_tile(rtn, rtn & 1);
         // Value only: the row sums of group j - 1 ride in the odd slots of group j (no padding; measured faster
         // at four waves per SIMD).  With the gradient (two waves per SIMD) the padded steps in the group's own
@@ -673,6 +682,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
 #pragma unroll
     for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
       const int k = wave + FW * q;
+      if (q == 0) { if (wave < FW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+      else { if (wave < FW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       if (k < K) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {        // 32-row pairs: k index j <-> row 32 m + 16 (j >> 2) + 4 g + (j & 3)
