@@ -75,6 +75,7 @@
 // the accumulator registers 8 s .. 8 s + 7 as the A operand of the second product's k-step s) took the same number
 // of cycles but ran at 1.71 - 1.75 GHz, 6.4 ms against 5.8 ms, and was dropped.
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include "bvi_common.h"
 
@@ -718,8 +719,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // slot, reaches the tile's barrier early and waits there while the other finishes on its own.  Handing the
         // priority over in the middle of the tile lets the second one catch up before the barrier (measured 1.3 - 2 %;
         // other hand-over points gained less or lost, a late one -- three units to one -- 17 %).
-        if constexpr (j == 0) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if constexpr (j == UPT / 2) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        // (8-wave workgroups only: with 4 waves the SIMD's other wave belongs to another workgroup, at its own place)
+        if constexpr (NW == 8 && j == 0) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        if constexpr (NW == 8 && j == UPT / 2) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
         const unsigned char* ia = j + 2 < UPT ? icur : inxt;
         const unsigned char* iy = j + (UNI ? 2 : 1) < UPT ? icur : inxt;
         static_for<NS>([&](auto sc_) {
@@ -1355,7 +1357,7 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   const size_t lds = (pipelined ? 3 : 2) * (size_t)(kTileRows * 2 * D + kTileRows * 4);
   // > 64 KB of dynamic LDS has to be allowed once per kernel and device (setting it twice from two threads is
   // harmless)
-  static bool lds_ok[64] = {};
+  static std::atomic<bool> lds_ok[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return BVI_ERR_ARG;
   if (!lds_ok[dev]) {
