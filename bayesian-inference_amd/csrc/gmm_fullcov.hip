@@ -430,6 +430,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   __shared__ float lpw[FT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lead_wave = __builtin_amdgcn_readfirstlane(wave) < FW / 2;      // wave-uniform, in a scalar register
   const int ln = lane & 15, g = lane >> 4;
   const int c = blockIdx.y;
   auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };
@@ -575,12 +576,13 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
         const int jn = j + 1, rtn = jn / KQ, qn = jn % KQ;
         // The two waves of a SIMD (w and w + FW / 2) run the same stream between the same barriers; left alone the
         // older one wins every issue slot, reaches the barrier early and waits while the other finishes on its
-        // own.  Handing the priority over in the middle of a phase lets the second one catch up: here waves 0 - 3
-        // first, in the raw-sums phase below waves 4 - 7 first (13.6 -> 13.0 ms; this phase alone 13.35, the other
-        // orders of the raw-sums phase slower than none).
-        if (GRAD) {
-          if (j == 0) { if (wave < FW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-          if (j == NG / 2) { if (wave < FW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        // own.  Issue priorities by phase, found by measurement (13.6 ms without any -> 12.9 ms; the eighteen other
+        // patterns tried lie between 13.2 and 13.9): first half of this phase both waves high, second half and the
+        // first half of the raw-sums phase below waves 4 - 7 high, its second half waves 0 - 3.  The condition has to
+        // sit in a scalar register (on a per-lane condition both s_setprio are executed by every wave).
+        if (GRAD && (j == 0 || j == NG / 2)) {
+          if (j == 0 || !lead_wave) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
         }
         if (jn < NG && qn == 0) load_tile(rtn, rtn & 1);
         // Value only: the row sums of group j - 1 ride in the odd slots of group j (no padding; measured faster
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
 #pragma unroll
     for (int q = 0; q < (GRAD ? KQ : 0); ++q) {
       const int k = wave + FW * q;
-      if (q == 0) { if (wave < FW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-      else { if (wave < FW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      if (lead_wave == (q != 0)) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
       if (k < K) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {        // 32-row pairs: k index j <-> row 32 m + 16 (j >> 2) + 4 g + (j & 3)

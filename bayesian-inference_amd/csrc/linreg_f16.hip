@@ -506,6 +506,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lead_wave = __builtin_amdgcn_readfirstlane(wave) < NW / 2;      // wave-uniform, in a scalar register
   const int ln = lane & 15, g = lane >> 4;
   const int x8 = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
@@ -717,11 +718,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr int ua = (j + 2) % UPT, uy = (j + (UNI ? 2 : 1)) % UPT;
         // The two waves of a SIMD (w and w + NW / 2) run the same stream; left alone the older one wins every issue
         // slot, reaches the tile's barrier early and waits there while the other finishes on its own.  Handing the
-        // priority over in the middle of the tile lets the second one catch up before the barrier (measured 1.3 - 2 %;
-        // other hand-over points gained less or lost, a late one -- three units to one -- 17 %).
-        // (8-wave workgroups only: with 4 waves the SIMD's other wave belongs to another workgroup, at its own place)
-        if constexpr (NW == 8 && j == 0) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if constexpr (NW == 8 && j == UPT / 2) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+        // priority over in the middle of the tile lets the second one catch up before the barrier (1.8 % against no
+        // priorities at all; every other pattern of the four units measured gained less or lost, three units to one
+        // 15 %).  8-wave workgroups only: with 4 waves the SIMD's other wave belongs to another workgroup.  The
+        // condition has to sit in a scalar register: on a per-lane condition both s_setprio are executed by every wave.
+        if constexpr (NW == 8 && (j == 0 || j == UPT / 2)) {
+          if (lead_wave == (j == 0)) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
         const unsigned char* ia = j + 2 < UPT ? icur : inxt;
         const unsigned char* iy = j + (UNI ? 2 : 1) < UPT ? icur : inxt;
         static_for<NS>([&](auto sc_) {
