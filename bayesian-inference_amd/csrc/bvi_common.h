@@ -79,6 +79,26 @@ __device__ __forceinline__ double bvi_sum_partials(const float* __restrict__ p, 
   return s;
 }
 
+// Issue priority of the calling wave: 1 if `high` (the same in every lane; all lanes active), else 0.  One asm
+// statement with the branch inside it, so that the surrounding loop body stays one basic block: a C-level if / else
+// splits it, and the compiler then moves instructions across the split that the hand-made schedule had placed (the
+// sums of squares of a tile's first half were sunk into its second half).  The flag is compared in a vector
+// register: under register pressure a wave-uniform value may live in one, whatever the operand constraint says.
+__device__ __forceinline__ void bvi_set_priority(bool high) {
+  asm volatile(
+      "v_cmp_ne_u32_e32 vcc, 0, %0\n\t"
+      "s_nop 4\n\t"
+      "s_cbranch_vccz .Lbvi_prio_lo_%=\n\t"
+      "s_setprio 1\n\t"
+      "s_branch .Lbvi_prio_end_%=\n"
+      ".Lbvi_prio_lo_%=:\n\t"
+      "s_setprio 0\n"
+      ".Lbvi_prio_end_%=:"
+      :
+      : "v"((int)high)
+      : "vcc");
+}
+
 // Sum over the lanes that share (lane % CP): butterfly over the upper lane bits.
 template <int CP>
 __device__ __forceinline__ float bvi_reduce_over_rowsubs(float v) {

@@ -722,10 +722,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // priorities at all; every other pattern of the four units measured gained less or lost, three units to one
         // 15 %).  8-wave workgroups only: with 4 waves the SIMD's other wave belongs to another workgroup.  The
         // condition has to sit in a scalar register: on a per-lane condition both s_setprio are executed by every wave.
-        if constexpr (NW == 8 && (j == 0 || j == UPT / 2)) {
-          if (lead_wave == (j == 0)) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
-        }
+        if constexpr (NW == 8 && (j == 0 || j == UPT / 2)) bvi_set_priority(lead_wave == (j == 0));
         const unsigned char* ia = j + 2 < UPT ? icur : inxt;
         const unsigned char* iy = j + (UNI ? 2 : 1) < UPT ? icur : inxt;
         static_for<NS>([&](auto sc_) {
