@@ -613,16 +613,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // one scale per block: the staged targets are T (y - ybar), padding rows exact zeros
   const float ypad = uni ? 0.f : pad_value(centred_intercept_frag<KS>(theta + (int64_t)cbi * (16 * CT * NW) * (dr + 2), hdr->shift, dr, g, ybar));
   const float ymul = uni ? T : 1.f;
+  // per-thread byte offsets inside a tile (32 bits, fixed for the whole launch); the tile's own base is wave-uniform
+  // and stays in scalar registers, so a load is one instruction with no 64-bit vector arithmetic in front of it
+  unsigned xoff[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int idx = tid + e * NT;
+    const int srow = (NCH % NT == 0 || idx < NCH) ? idx / TPR : 0, ch = idx % TPR;
+    xoff[e] = (unsigned)((srow * D + ch * 8) * 2);
+  }
+  const unsigned yoff = (unsigned)((tid / YT) * 4);
   auto gload = [&](int64_t k) {      // k-th tile of this row block; past the end: tile 0 of the dataset, never used
     const int64_t tile = rbi + k * nrb;
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
+    const unsigned char* xbase = planes + row0 * (D * 2);
+    const unsigned char* ybase = yplane + row0 * 4;
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int idx = tid + e * NT;
-      const int srow = (NCH % NT == 0 || idx < NCH) ? idx / TPR : 0, ch = idx % TPR;
-      xp[e] = *reinterpret_cast<const s16x8*>(planes + ((row0 + srow) * D + ch * 8) * 2);
-    }
-    yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
+    for (int e = 0; e < PER; ++e) xp[e] = *reinterpret_cast<const s16x8*>(xbase + xoff[e]);
+    yp = *reinterpret_cast<const float*>(ybase + yoff);
     yvalid = row0 + tid / YT < n;      // (the arithmetic on yp waits until the store: no wait for the load here)
   };
   auto lstore = [&](int ring) {
