@@ -69,6 +69,14 @@ int main() {
   run<Slot<'A', 'A', 'F'>, Slot<'S', 'S', 'F'>, Slot<'C', 'C'>>("mask: [and and fma] [sub sub fma] [cvt cvt]", d);
   run<Slot<'A', 'S', 'F'>, Slot<'A', 'S', 'F'>, Slot<'C', 'C'>>("mask: [and sub fma] [and sub fma] [cvt cvt]", d);
   run<Slot<'A', 'A', 'S'>, Slot<'S', 'C', 'F'>, Slot<'C', 'F'>>("mask: [and and sub] [sub cvt fma] [cvt fma]", d);
+  run<Slot<'C', 'F'>, Slot<'F', 'L'>, Slot<'H'>>("[cvt fma] [fma mixlo] [mixhi]", d);
+  run<Slot<'F', 'C'>, Slot<'L', 'F'>, Slot<'H'>>("[fma cvt] [mixlo fma] [mixhi]", d);
+  run<Slot<'F', 'C'>, Slot<'F', 'L'>, Slot<'H'>>("[fma cvt] [fma mixlo] [mixhi]", d);
+  run<Slot<'C'>, Slot<'L', 'F'>, Slot<'F', 'H'>>("[cvt] [mixlo fma] [fma mixhi]", d);
+  run<Slot<'C'>, Slot<'F', 'L'>, Slot<'F', 'H'>>("[cvt] [fma mixlo] [fma mixhi]", d);
+  run<Slot<'C', 'L'>, Slot<'F', 'F'>, Slot<'H'>>("[cvt mixlo] [fma fma] [mixhi]", d);
+  run<Slot<'C', 'L'>, Slot<'H', 'F'>, Slot<'F'>>("[cvt mixlo] [mixhi fma] [fma]", d);
+  run<Slot<'C', 'L'>, Slot<'H'>, Slot<'F', 'F'>>("[cvt mixlo] [mixhi] [fma fma]", d);
   run<Slot<'C', 'F', 'F'>, Slot<'L'>, Slot<'H'>>("[cvt fma fma] [mixlo] [mixhi]", d);
   run<Slot<'C', 'F'>, Slot<'L'>, Slot<'H', 'F'>>("[cvt fma] [mixlo] [mixhi fma]", d);
   return 0;
