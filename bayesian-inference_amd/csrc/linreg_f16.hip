@@ -109,7 +109,9 @@ constexpr int kColTop = 4;
 // w / s_d; an all-zero column (s_d = 0) takes no part in the chain's range (0, or NaN for a
 // non-finite weight, as 0 * w would give)
 __device__ __forceinline__ float scaled_weight(float w, float colscale) {
-  return colscale > 0.f ? w / colscale : w * 0.f;
+  // colscale is a power of two: w / colscale as one exponent shift, exact, no division and no branch
+  const float q = __builtin_amdgcn_ldexpf(w, 1 - __builtin_amdgcn_frexp_expf(colscale));
+  return colscale > 0.f ? q : w * 0.f;
 }
 
 __device__ __forceinline__ float col_scale(float amax) {
@@ -137,15 +139,38 @@ __device__ __forceinline__ float chain_scale(float amax_v, float b0, float ymax,
 // shift_f w_f (0 beyond the model's features), added as a butterfly over the feature index (f ^ 32, 16, ..., 1),
 // then (b0 - ybar) + sum, every operation rounded on its own (no contraction).
 // Here: for a lane of the matrix kernels, which holds features 32 ks + 8 g + j of its chain (g = lane >> 4).
+// The weights and column scales of features 32 ks + 8 g + j of one chain, all loads issued before the first is waited
+// for (left to itself the compiler makes every load conditional on its feature being one of the model's and waits
+// for each in turn: sixteen round trips to memory in the prologue of every workgroup).
+template <int KS>
+__device__ __forceinline__ void load_weight_fragment(const float* __restrict__ th, const float* __restrict__ colscale,
+                                                     int dr, int g, float (&wr)[KS][8], float (&cs)[KS][8]) {
+  // (colscale: any per-feature array of 64 floats in the header -- the column scales or the shifts)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 32 * ks + 8 * g + j;
+      wr[ks][j] = th[1 + (f < dr ? f : 0)];
+      cs[ks][j] = colscale[f];
+    }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wr[ks][j]), "+v"(cs[ks][j]));
+}
+
 template <int KS>
 __device__ __forceinline__ float centred_intercept_frag(const float* __restrict__ th,
                                                         const float* __restrict__ shift, int dr, int g, float ybar) {
+  float wr[KS][8], m[KS][8];
+  load_weight_fragment<KS>(th, shift, dr, g, wr, m);      // (all loads in flight together)
   float a[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int f0 = 8 * g + j, f1 = 32 + 8 * g + j;
-    const float p0 = f0 < dr ? __fmul_rn(shift[f0], th[1 + f0]) : 0.f;
-    const float p1 = (KS == 2 && f1 < dr) ? __fmul_rn(shift[f1], th[1 + f1]) : 0.f;
+    const float p0 = f0 < dr ? __fmul_rn(m[0][j], wr[0][j]) : 0.f;
+    const float p1 = (KS == 2 && f1 < dr) ? __fmul_rn(m[KS - 1][j], wr[KS - 1][j]) : 0.f;
     a[j] = __fadd_rn(p0, p1);                                   // f ^ 32
   }
 #pragma unroll
@@ -253,12 +278,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
       const bool cvalid = chain < C;
       const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
       float v[KS][8], amax = 0.f;
+      float wr[KS][8], cs[KS][8];
+      load_weight_fragment<KS>(th, hdr->colscale, dr, g, wr, cs);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int f = 32 * ks + 8 * g + j;
-          v[ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
+          v[ks][j] = (cvalid && f < dr) ? -scaled_weight(wr[ks][j], cs[ks][j]) : 0.f;
           amax = fmaxf(amax, fabsf(v[ks][j]));
         }
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));   // the four lane groups hold the chain's D features
@@ -297,18 +324,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   // {0-3,12-15,20-27}, ...: 16 rows, two neighbouring chunks), the transposed ds_read_b64_tr_b16 (32 lanes:
   // 8 rows x 32 B) and the 128-bit row stores all spread over the 64 banks without conflicts
   auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
-  s16x8 xp[PER];
-  float yp;
-  bool yvalid;
+  // staged through registers two tiles ahead (two register sets, taken in turn): at few chains a tile's arithmetic is
+  // a fraction of the HBM latency, and with one tile in flight per workgroup the loads' latency, not the memory
+  // system's pace, set the time
+  s16x8 xp[2][PER];
+  float yp[2];
+  bool yvalid[2];
   const float ybar = hdr->ybar;
   const float ypad = pad_value(centred_intercept_frag<KS>(theta + (int64_t)cbi * (16 * CT * NW) * (dr + 2), hdr->shift, dr, g, ybar));
-  auto gload = [&](int64_t tile) {
+  auto gload = [&](int64_t tile, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     const int64_t row0 = (tile < ntiles ? tile : 0) * kTileRows;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       const int idx = tid + e * NT;
       const int srow = (NCH % NT == 0 || idx < NCH) ? idx / TPR : 0, ch = idx % TPR;
-      xp[e] = *reinterpret_cast<const s16x8*>(planes + ((row0 + srow) * D + ch * 8) * 2);
+      xp[S][e] = *reinterpret_cast<const s16x8*>(planes + ((row0 + srow) * D + ch * 8) * 2);
     }
     // every thread stages a y (NW threads per row, same value): an unconditional use keeps the
     // compiler from sinking this load down to the store, where its latency would be exposed
@@ -316,32 +347,39 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     // workgroup's first chain their residuals, t (ypad - (b0 - ybar)), are zero for that chain and of the size of
     // the chains' spread for the others -- small next to the real rows' sum -- and the finalize kernel takes
     // their squares out of S2' again
-    yp = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
-    yvalid = row0 + tid / YT < n;      // (the arithmetic on yp waits until the store: no wait for the load here)
+    yp[S] = *reinterpret_cast<const float*>(yplane + (row0 + tid / YT) * 4);
+    yvalid[S] = row0 + tid / YT < n;      // (the arithmetic on yp waits until the store: no wait for the load here)
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     unsigned char* base = lds + buf * BUF;
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
       const int idx = tid + e * NT;
       const int srow = idx / TPR, ch = idx % TPR;
       if (NCH % NT == 0 || idx < NCH)
-        *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[e];
+        *reinterpret_cast<s16x8*>(base + srow * SA + ((ch ^ swz(srow)) << 4)) = xp[S][e];
     }
-    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid ? yp - ybar : ypad;
+    *reinterpret_cast<float*>(base + IMG + (tid / YT) * 4) = yvalid[S] ? yp[S] - ybar : ypad;
   };
 
   // slot behind the partials that tells the finalize kernel how this chain block was scaled: 0 = one scale per chain
   if (rbi == 0 && tid == 0) partials[(int64_t)nrb * C * (dr + 2) + cbi] = 0.f;
   int64_t tile = rbi;
+  constexpr std::integral_constant<int, 0> set0{};
+  constexpr std::integral_constant<int, 1> set1{};
   if (tile < ntiles) {
-    gload(tile);
-    lstore(0);
+    gload(tile, set0);
+    lstore(0, set0);
+    gload(tile + nrb, set1);      // past the end: re-reads tile 0, never used
   }
   __syncthreads();
   int buf = 0;
-  for (; tile < ntiles; tile += nrb) {
-    gload(tile + nrb);   // past the end: re-reads tile 0, never used
+  // iteration k (parity P = k % 2): loads tile k + 2 into register set P, multiplies tile k from LDS, stores tile k + 1
+  // (register set 1 - P, loaded during iteration k - 1) into the other LDS buffer
+  auto iteration = [&](auto par_c) {
+    constexpr int P = decltype(par_c)::value;
+    gload(tile + 2 * (int64_t)nrb, std::integral_constant<int, P>{});
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* base = lds + buf * BUF;
     float a2[CT];               // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
@@ -427,9 +465,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) s2[ct] += (double)a2[ct];
-    lstore(buf ^ 1);     // as late as possible: the whole tile's arithmetic covers the HBM latency of gload
+    lstore(buf ^ 1, std::integral_constant<int, 1 - P>{});
     __syncthreads();
     buf ^= 1;
+  };
+  while (tile < ntiles) {
+    iteration(set0);
+    tile += nrb;
+    if (tile >= ntiles) break;
+    iteration(set1);
+    tile += nrb;
   }
 
 #pragma unroll
@@ -541,12 +586,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const bool cvalid = chain < C;
       const float* th = theta + (int64_t)(cvalid ? chain : 0) * (dr + 2);
       float amax = 0.f;
+      float wr[KS][8], cs[KS][8];
+      load_weight_fragment<KS>(th, hdr->colscale, dr, g, wr, cs);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int f = 32 * ks + 8 * g + j;
-          v[ct][ks][j] = (cvalid && f < dr) ? -scaled_weight(th[1 + f], hdr->colscale[f]) : 0.f;
+          v[ct][ks][j] = (cvalid && f < dr) ? -scaled_weight(wr[ks][j], cs[ks][j]) : 0.f;
           amax = fmaxf(amax, fabsf(v[ct][ks][j]));
         }
       amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
