@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 106
+#define BVI_VERSION 107
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
