@@ -798,12 +798,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             YV[UNI ? sq : sr][rt] = read_y(iy, uy, rt);
           }
           // -- the slot's MFMA
-          if constexpr (r == 2) {                          // P(j+1): row tile rt, k-step ks, chain tile ct
+          constexpr int kPSlot = 0;                        // the group's P first, then its two R (0.4 % over R, R, P)
+          if constexpr (r == kPSlot) {                     // P(j+1): row tile rt, k-step ks, chain tile ct
             constexpr int rt = grp / (CT * KS), ks = (grp / CT) % KS, ct = grp % CT;
             Z[sr][rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                 A[sr][rt][ks], w1[ct][ks], ks == 0 ? (UNI ? YV[sr][rt] : nb0v[ct]) : Z[sr][rt][ct], 0, 0, 0);
           } else {                                         // R(j-1): feature tile ft, piece, chain tile ct
-            constexpr int q = 2 * grp + r, ft = q / (2 * CT), piece = (q % (2 * CT)) / CT, ct = q % CT;
+            constexpr int rr = r - (r > kPSlot ? 1 : 0);
+            constexpr int q = 2 * grp + rr, ft = q / (2 * CT), piece = (q % (2 * CT)) / CT, ct = q % CT;
             const f16x8 rv = piece == 0
                 ? __builtin_bit_cast(f16x8, (u32x4){RH[sr][ct][0], RH[sr][ct][1], RH[sr][ct][2], RH[sr][ct][3]})
                 : __builtin_bit_cast(f16x8, (u32x4){RL[sr][ct][0], RL[sr][ct][1], RL[sr][ct][2], RL[sr][ct][3]});
