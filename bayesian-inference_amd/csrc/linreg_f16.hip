@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
   const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
   // CT chain tiles of 16 per wave: 2 for the many-chain shapes, 1 when at most 16 NW chains are asked for
   const int cbase = cbi * (16 * CT * NW) + 16 * CT * wave;
+  const bool wave_has_chains = __builtin_amdgcn_readfirstlane(cbase) < C;      // wave-uniform, in a scalar register
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
   const int64_t n_pad = ntiles * kTileRows;
@@ -385,6 +386,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(CT == 1
     float a2[CT];               // this tile's sum of squares: two-level summation keeps S2 to ~1e-7
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) a2[ct] = 0.f;
+    // a wave whose chain tiles all lie beyond the last chain only helps with the staging (with 1 - 16 chains three of
+    // the four waves: the tile then costs a quarter of the matrix and vector work and the pass runs at the memory
+    // system's pace)
+    if (wave_has_chains)
 #pragma unroll
     for (int sub = 0; sub < kTileRows / 64; ++sub) {
     const int ro = 64 * sub;
@@ -556,6 +561,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const int x8 = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int cbi = jj % ncb, rbi = (jj / ncb) * 8 + x8;
   const int cbase = cbi * (16 * CT * NW) + 16 * CT * wave;
+  // a wave whose chain tiles all lie beyond the last chain (a partly filled chain block) only helps with the staging
+  const bool wave_has_chains = __builtin_amdgcn_readfirstlane(cbase) < C;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
   const int64_t n_pad = ntiles * kTileRows;
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     gload(0); lstore(0);
     gload(1); lstore(1);
     __syncthreads();
-    {
+    if (wave_has_chains) {
       const unsigned char* img = lds;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
@@ -765,6 +772,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const unsigned char* icur = lds + rcur * BUF;
       const unsigned char* inxt = lds + rnxt * BUF;
       __builtin_amdgcn_sched_barrier(0);
+      if (wave_has_chains)
       static_for<UPT>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int sq = j & 1, sr = (j + 1) & 1;      // sets: Q / loads of XH, A  |  R, P, loads of YV
@@ -865,6 +873,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       rcur = rnxt;
     }
     // epilogue: the gradient GEMM of the last unit
+    if (wave_has_chains)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
