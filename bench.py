@@ -340,20 +340,26 @@ def main():
         times.sort()
         ms16 = times[len(times) // 2]
         b16 = 4.0 * n_local * (d + 1) + 8.0 * c16 * (d + 2)
-        out['roofline_hbm_regime'] = {
+        alg = b16 / (ms16 * 1e-3) / 1e9
+        hbm = {
             'chains': c16,
             'kernel': ('linreg_f16_kernel<64, 4, 1> + linreg_f16_finalize' if fmt16 == _native.PACK_F16
                        else 'linreg_f32_kernel + linreg_finalize'),
-            'bound': 'hbm', 'ms': ms16,
-            'achieved': b16 / (ms16 * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'achieved_is': 'algorithmic bytes of the f32 dataset, 4 N (D+1), over the time',
-            'frac': b16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'grad_evals_per_s': c16 / (ms16 * 1e-3)}
+            'bound': 'hbm', 'ms': ms16, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'grad_evals_per_s': c16 / (ms16 * 1e-3),
+            # the algorithmic bytes of the f32 dataset, 4 N (D+1), over the time: what the metric's definition counts
+            'algorithmic_GBps': alg, 'algorithmic_frac': alg / HBM_PEAK_GBPS}
         if fmt16 == _native.PACK_F16:
-            # the kernel itself streams the packed f16 plane + y: these are the bytes DRAM actually delivers
+            # the kernel itself streams the packed f16 plane + y, half the algorithmic bytes (what the plane leaves
+            # out is added in closed form): `achieved` / `frac` are the bytes DRAM actually delivers over the time
             dram = 2.0 * n_local * (32 if d <= 32 else 64) + 4.0 * n_local
-            out['roofline_hbm_regime']['dram_bytes_per_launch'] = dram
-            out['roofline_hbm_regime']['dram_GBps'] = dram / (ms16 * 1e-3) / 1e9
-            out['roofline_hbm_regime']['dram_frac'] = dram / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            hbm.update({'achieved': dram / (ms16 * 1e-3) / 1e9, 'frac': dram / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        'achieved_is': 'bytes of the packed f16 plane + y that the kernel reads, over the time',
+                        'dram_bytes_per_launch': dram})
+        else:
+            hbm.update({'achieved': alg, 'frac': alg / HBM_PEAK_GBPS,
+                        'achieved_is': 'algorithmic bytes of the f32 dataset, 4 N (D+1), over the time'})
+        out['roofline_hbm_regime'] = hbm
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(n, d)
     if rank == 0:
