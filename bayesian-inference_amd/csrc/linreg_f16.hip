@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
   const int64_t tot = (int64_t)C * q2;
   const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
   __shared__ double part[5][kFinGroups][64];
-  __shared__ double sums[66], dw[64], wv[64], s2t[64];
+  __shared__ double sums[66], dw[64], wv[64];
   __shared__ float sh_t, sh_b0c, sh_pad;
   __shared__ double sh_bt, sh_s1;
   const Header* hdr = reinterpret_cast<const Header*>(packed);
@@ -1249,18 +1249,34 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
       sh_s1 = hdr->ysum - nn * ((double)th[0] + mw) - wc;
     }
   }
-  for (int q0 = 0; q0 < q2; q0 += 64) {
-    const int q = q0 + o;
-    double s = 0.0;
-    if (q < q2) {
+  {
+    // the chain's q2 = d + 2 <= 66 raw sums over the row blocks: lane o takes sum o and, for the one or two sums
+    // beyond the 64th, a second accumulator in the same loop (one pass over the partials, one exchange)
+    const float* pc = partials + (int64_t)c * q2;
+    const bool first = o < q2, extra = 64 + o < q2;
+    double s = 0.0, sx = 0.0;
+    // (loads unconditional, from clamped indices, so that a whole unrolled batch is in flight at once)
+    const int i0 = first ? o : 0, i1 = extra ? 64 + o : i0;
+    if (q2 > 64) {
+#pragma unroll 8
+      for (int b = grp; b < nb; b += kFinGroups) {
+        s += (double)pc[(int64_t)b * tot + i0];
+        sx += (double)pc[(int64_t)b * tot + i1];
+      }
+    } else {
 #pragma unroll 16
-      for (int b = grp; b < nb; b += kFinGroups) s += (double)partials[(int64_t)b * tot + (int64_t)c * q2 + q];
+      for (int b = grp; b < nb; b += kFinGroups) s += (double)pc[(int64_t)b * tot + i0];
     }
     part[0][grp][o] = s;
+    part[1][grp][o] = sx;
     __syncthreads();
-    if (grp == 0 && q < q2) {
-      for (int w = 1; w < kFinGroups; ++w) s += part[0][w][o];
-      sums[q] = s;
+    if (grp == 0) {
+      for (int w = 1; w < kFinGroups; ++w) {
+        s += part[0][w][o];
+        sx += part[1][w][o];
+      }
+      if (first) sums[o] = s;
+      if (extra) sums[64 + o] = sx;
     }
     __syncthreads();
   }
@@ -1293,48 +1309,52 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     part[4][grp][o] = cbd;
   }
   __syncthreads();
-  if (threadIdx.x < d) {
-    const int f = threadIdx.x;
-    const double cs = (double)hdr->colscale[f];
-    double m[5];
+  if (grp == 0) {
+    const int f = o;
+    double sv = 0.0;      // this feature's share of the corrections to S2
+    if (f < d) {
+      const double cs = (double)hdr->colscale[f];
+      double m[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      m[k] = part[k][0][f];
-      for (int w = 1; w < kFinGroups; ++w) m[k] += part[k][w][f];
+      for (int k = 0; k < 5; ++k) {
+        m[k] = part[k][0][f];
+        for (int w = 1; w < kFinGroups; ++w) m[k] += part[k][w][f];
+      }
+      // kernel: r_k = y - b0_eff - xh.wk with wk = w - dw and b0_eff = b0 - db, G_k = sum xh r_k
+      // (G'_f = t s_f G_k,f).  The true residual is r = r_k - (db + xr.w + xh.dw), hence
+      //   G = G_k - A wk - (X^T X) dw + t1 - db XH^T 1,   t1 = XR^T y - b0 XR^T 1,   XH^T 1 = X^T 1 - XR^T 1
+      //   S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B wk + dw . (X^T X - A) dw)
+      //        - 2 db (sum y - n b0_eff - w . X^T 1) + n db^2,   cr = t1 + db XR^T 1 - B wk = sum xr r_k
+      // (db: -2 db sum r_k from the cross term, + 2 db (w . XR^T 1 + dw . XH^T 1) from the square of what was left
+      // out)
+      const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;
+      const double xr1 = low[8192 + 64 + f];
+      const double sxh = hdr->colsum[f] - xr1;
+      const double t1 = low[8192 + f] - bt * xr1;
+      const double bwk = m[3] - m[4];
+      sv = -2.0 * (wv[f] * (t1 + db * xr1 - bwk) + dw[f] * g0) + wv[f] * (m[1] - 2.0 * bwk) + dw[f] * (m[0] - m[2]) +
+           2.0 * db * wv[f] * (sxh + xr1);
+      // (the sums are those of the centred columns: d/dw_f = sum_i (x~_if + shift_f) r_i)
+      if (grad)
+        grad[(int64_t)c * q2 + 1 + f] =
+            (float)((g0 - (m[1] - m[2]) - m[0] + t1 - db * sxh + (double)hdr->shift[f] * sh_s1) * inv2);
     }
-    // kernel: r_k = y - b0_eff - xh.wk with wk = w - dw and b0_eff = b0 - db, G_k = sum xh r_k
-    // (G'_f = t s_f G_k,f).  The true residual is r = r_k - (db + xr.w + xh.dw), hence
-    //   G = G_k - A wk - (X^T X) dw + t1 - db XH^T 1,   t1 = XR^T y - b0 XR^T 1,   XH^T 1 = X^T 1 - XR^T 1
-    //   S2 = S2_k - 2 (w . cr + dw . G_k) + (w . A w - 2 w . B wk + dw . (X^T X - A) dw)
-    //        - 2 db (sum y - n b0_eff - w . X^T 1) + n db^2,   cr = t1 + db XR^T 1 - B wk = sum xr r_k
-    // (db: -2 db sum r_k from the cross term, + 2 db (w . XR^T 1 + dw . XH^T 1) from the square of what was left out)
-    const double g0 = cs > 0.0 ? sums[2 + f] / (u * cs) : sums[2 + f] * 0.0;
-    const double xr1 = low[8192 + 64 + f];
-    const double sxh = hdr->colsum[f] - xr1;
-    const double t1 = low[8192 + f] - bt * xr1;
-    const double bwk = m[3] - m[4];
-    s2t[f] = -2.0 * (wv[f] * (t1 + db * xr1 - bwk) + dw[f] * g0) + wv[f] * (m[1] - 2.0 * bwk) + dw[f] * (m[0] - m[2]) +
-             2.0 * db * wv[f] * (sxh + xr1);
-    // (the sums are those of the centred columns: d/dw_f = sum_i (x~_if + shift_f) r_i)
-    if (grad)
-      grad[(int64_t)c * q2 + 1 + f] =
-          (float)((g0 - (m[1] - m[2]) - m[0] + t1 - db * sxh + (double)hdr->shift[f] * sh_s1) * inv2);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // padding rows of the last tile came through as r' = fma(ypad, t, -t (b0 - ybar)): out again
-    const double npad = (double)((n + kTileRows - 1) / kTileRows * kTileRows - n);
-    // (with one scale per block the padding rows are exact zeros)
-    const float rpad = block_scale > 0.f
-                           ? 0.f
-                           : fmaf(sh_pad, sh_t, -b0c * sh_t);
-    double s2 = (sums[0] + sums[1] - npad * (double)rpad * (double)rpad) / (u * u);   // S2' arrives as a float pair
-    s2 += -2.0 * db * (hdr->ysum - nn * b0_eff) + nn * db * db;
-    for (int f = 0; f < d; ++f) s2 += s2t[f];
-    logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D - (ref ? *ref : 0.0));
-    if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
-  } else if (threadIdx.x == 64 && grad) {
-    grad[(int64_t)c * q2] = (float)(sh_s1 * inv2);
+    // sum over the features: a butterfly (fixed order), every lane ends with the total
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
+    if (o == 0) {
+      // padding rows of the last tile came through as r' = fma(ypad, t, -t (b0 - ybar)): out again
+      // (with one scale per block the padding rows are exact zeros)
+      const double npad = (double)((n + kTileRows - 1) / kTileRows * kTileRows - n);
+      const float rpad = block_scale > 0.f ? 0.f : fmaf(sh_pad, sh_t, -b0c * sh_t);
+      double s2 = (sums[0] + sums[1] - npad * (double)rpad * (double)rpad) / (u * u);   // S2' arrives as a float pair
+      s2 += -2.0 * db * (hdr->ysum - nn * b0_eff) + nn * db * db;
+      s2 += sv;
+      logp[c] = (float)(-0.5 * s2 * inv2 - nn * log(sc) - 0.5 * nn * BVI_LN2PI_D - (ref ? *ref : 0.0));
+      if (grad) grad[(int64_t)c * q2 + d + 1] = (float)(-nn / sc + s2 * inv2 / sc);
+    } else if (o == 1 && grad) {
+      grad[(int64_t)c * q2] = (float)(sh_s1 * inv2);
+    }
   }
 }
 
