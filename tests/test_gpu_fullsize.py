@@ -11,6 +11,8 @@ import torch
 
 from parity_util import RTOL
 
+# gradients are judged against the largest entry of the chain alone: no floor proportional to the summed terms
+FLOOR = 0.0
 pytestmark = pytest.mark.gpu
 
 
@@ -80,10 +82,10 @@ def test_regression_10m_rows_1024_chains_against_float64_statistics(nat, ws, reg
     assert bool(torch.isfinite(lp).all()) and bool(torch.isfinite(g).all())
     _close(lp, ref_lp, ref_lp.abs(), what='logp f16 pieces')
     gmax = ref_g.abs().max(-1, keepdim=True).values
-    _close(g, ref_g, gmax + 3e-2 * term, what='grad f16 pieces')
+    _close(g, ref_g, gmax + FLOOR * term, what='grad f16 pieces')
     lp32, g32 = nat.linreg_logp_grad(r['X'], r['y'], th[:64].contiguous(), ws, precision=nat.PREC_F32)
     _close(lp32, ref_lp[:64], ref_lp[:64].abs(), what='logp f32')
-    _close(g32, ref_g[:64], gmax[:64] + 3e-2 * term[:64], what='grad f32')
+    _close(g32, ref_g[:64], gmax[:64] + FLOOR * term[:64], what='grad f32')
     # determinism at full size
     lp2, g2 = nat.linreg_packed_logp_grad(pk, n, d, th, ws, fmt=nat.PACK_F16)
     assert torch.equal(lp, lp2) and torch.equal(g, g2)
@@ -110,7 +112,7 @@ def test_regression_10m_rows_few_chains_through_the_host_mirror(nat, ws, regress
     lp, g = lik.logp_grad(th)
     ref_lp, ref_g, term = _reference_from_stats(r, th)
     _close(lp, ref_lp, ref_lp.abs(), what='logp')
-    _close(g, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='grad')
+    _close(g, ref_g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * term, what='grad')
     lp_v, _ = lik.logp_grad(th, want_grad=False)
     assert torch.equal(lp, lp_v)
 
@@ -243,7 +245,7 @@ def test_regression_10m_row_shards_add(nat, ws, regression_10m):
     gs = parts[0][1].double() + parts[1][1].double()
     _, ref_g, term = _reference_from_stats(r, th)
     _close(lps, lp, lp.abs(), what='logp shards')
-    _close(gs, g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='grad shards')
+    _close(gs, g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * term, what='grad shards')
 
 
 def test_regression_10m_rescaling_property(nat, ws, regression_10m):
@@ -262,7 +264,7 @@ def test_regression_10m_rescaling_property(nat, ws, regression_10m):
     _, ref_g, term = _reference_from_stats(r, r['th'][:256])
     _close(lpa.double() + n * math.log(a), lp, lp.abs(), rtol=2 * RTOL, what='logp rescaled')
     # y, theta were re-rounded to f32 after scaling: allow the f32 input rounding on top (2x)
-    _close(ga.double() * a, g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, rtol=3 * RTOL,
+    _close(ga.double() * a, g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * term, rtol=3 * RTOL,
            what='grad rescaled')
 
 
@@ -325,7 +327,7 @@ def test_mixture_component_table(nat, ws, gpu_device, n, case):
     sel = torch.tensor([0, 1, 2, c - 1], device=gpu_device)
     ref_lp, ref_g, absg = _mixture_float64(y, th[sel], k)
     _close(lp[sel], ref_lp, ref_lp.abs(), what='mixture logp (%s)' % case)
-    _close(gr[sel], ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg, what='mixture grad (%s)' % case)
+    _close(gr[sel], ref_g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * absg, what='mixture grad (%s)' % case)
     bad = th.clone(); bad[1, k + 1] = float('nan')
     lpb, grb = nat.gmm1d_logp_grad(y, bad, k, ws)
     assert bool(torch.isnan(lpb[1])) and bool(torch.isfinite(lpb[[0, 2]]).all())
@@ -366,7 +368,7 @@ def test_mixture_few_chains_rows_in_ascending_order(nat, ws, gpu_device, c, case
         lpv, _ = nat.gmm1d_logp_grad(rows, th, k, ws, want_grad=False)
         _close(lp, ref_lp, ref_lp.abs(), what='mixture logp, %d chains, rows %s (%s)' % (c, what, case))
         _close(lpv, ref_lp, ref_lp.abs(), what='mixture logp, value only, %d chains, rows %s (%s)' % (c, what, case))
-        _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg,
+        _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * absg,
                what='mixture grad, %d chains, rows %s (%s)' % (c, what, case))
     # an odd start (the 16-byte grid of the loads shifts) and non-finite inputs
     lpo, _ = nat.gmm1d_logp_grad(ys[1:], th, k, ws, want_grad=False)
@@ -400,9 +402,9 @@ def test_mixture_100m_rows(nat, ws, gpu_device):
     b = nat.gmm1d_logp_grad(y[cut:], th, k, ws)
     ref_lp, ref_g, absg = _mixture_float64(y, th[:2], k)
     _close(lp[:2], ref_lp, ref_lp.abs(), what='mixture logp')
-    _close(gr[:2], ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * absg, what='mixture grad')
+    _close(gr[:2], ref_g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * absg, what='mixture grad')
     _close(a[0].double() + b[0].double(), lp, lp.abs(), what='mixture logp shards')
-    scale = gr.abs().max(-1, keepdim=True).values.double() + 3e-2 * absg.max(0).values[None]
+    scale = gr.abs().max(-1, keepdim=True).values.double() + FLOOR * absg.max(0).values[None]
     _close(a[1].double() + b[1].double(), gr, scale, what='mixture grad shards')
     # differences between nearby chains, relative to a level: |logp| ~ 3.5e8, floats 32 apart.  The kernel's own
     # exp2 / log2 leave a common offset of a few nats (1e-8 of the total) that cancels between chains; what a
@@ -436,7 +438,7 @@ def test_normal_100m_rows(nat, ws, gpu_device):
     ref_g = torch.stack([r1 / sc ** 2, -n / sc + r2 / sc ** 3], -1)
     term = torch.stack([sa / sc ** 2, r2 / sc ** 3 + n / sc], -1)
     _close(lp, ref_lp, ref_lp.abs(), what='normal logp')
-    _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + 3e-2 * term, what='normal grad')
+    _close(gr, ref_g, ref_g.abs().max(-1, keepdim=True).values + FLOOR * term, what='normal grad')
     # differences between chains inside the posterior's width, relative to a level: |logp| ~ 2.5e8 (floats 16 apart)
     mu_hat = s1 / n; sd_hat = torch.sqrt(s2 / n - mu_hat ** 2)
     for cc, bar in ((64, 2e-2), (16, 0.5), (1, 0.5)):      # few chains: one float sum of ~400 rows per lane
@@ -571,7 +573,7 @@ def test_elbo_gradient_10m_rows_256_samples(regression_10m, gpu_device, regime):
     # error scale of a gradient entry: that of the per-sample likelihood gradients it averages
     tz = term.clone(); tz[:, d + 1] = tz[:, d + 1] * torch.sigmoid(zs)
     gmax = gth.abs().max(-1, keepdim=True).values
-    per_sample = RTOL * (gmax + 3e-2 * tz)
+    per_sample = RTOL * (gmax + FLOOR * tz)
     tol_loc = per_sample.mean(0)
     tol_raw = (per_sample * eps.double().abs()).mean(0) * torch.sigmoid(raw.double())
     assert abs(float(loss.detach()) - float(ref_loss)) <= RTOL * abs(float(ref_loss))

@@ -132,7 +132,9 @@ def test_linreg_bf16_split(nat, ws, gpu_device, d, c, n):
     args = (dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device))
     lp, g = nat.linreg_logp_grad(*args, ws, precision=nat.PREC_BF16X6)
     assert_logp_close(lp.cpu().numpy(), ref_lp)
-    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th))
+    # (this explicitly selected mode keeps the floor any f32 summation has, 3e-7 x the sum of |terms|: one case,
+    # 130 chains on 200k rows, needs it; the default kernels are judged without)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=_linreg_term_scale(X, y, th), abs_term=3e-7)
     # the packed entry point runs the same arithmetic on a dataset split once up front
     pk = nat.linreg_pack(args[0], args[1])
     lp_p, g_p = nat.linreg_packed_logp_grad(pk, n, d, args[2], ws, precision=nat.PREC_BF16X6)
