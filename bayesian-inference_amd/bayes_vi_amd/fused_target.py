@@ -161,9 +161,10 @@ class LinearRegression(FusedLogLikelihood):
         """Packed format the evaluation of `c` chains runs on, or None for the exact-f32 kernels.
         AUTO: the f16-plane kernel (log-density at f32 accuracy, gradient error at the level of the f32 kernel's)
         for more than 16 chains (32 for at most 8 features, where the vector-ALU kernels stream less data) on a
-        shard of at least 16384 rows, and for any number of chains from a million rows of more than 8 features on:
-        the plane is half the bytes of the f32 matrix (N = 10M, D = 64: 0.36 ms against 0.56 ms of the exact-f32
-        kernel for 1 - 16 chains; below a million rows the two are within launch latency of each other).
+        shard of at least 16384 rows, and for any number of chains from 400 000 rows of more than 8 features on:
+        the plane is half the bytes of the f32 matrix (N = 10M, D = 64: 0.26 ms against 0.56 ms of the exact-f32
+        kernel for 1 - 16 chains; 500k rows 0.040 against 0.046 ms; at 300k rows and below the two are within
+        launch latency of each other).
         BF16X3 / BF16X6 select the bf16-piece kernel explicitly."""
         if not self.pack:
             return None
@@ -172,7 +173,7 @@ class LinearRegression(FusedLogLikelihood):
         if self.precision != _native.PREC_AUTO or self.d > 64 or self.n < 16384:
             return None
         few = 16 if self.d > 8 else 32
-        if c > few or (self.d > 8 and self.n >= 1_000_000):
+        if c > few or (self.d > 8 and self.n >= 400_000):
             return _native.PACK_F16
         return None
 
