@@ -1437,6 +1437,10 @@ static int launch_f16(const unsigned char* pk, int64_t n, int d, const float* th
   const int max_blocks = NW == 8 ? kMaxRowBlocks : ((CT == 1 && n >= 1000000) ? 3 : 2) * kMaxRowBlocks;
   const int ncb = bvi_ceil_div(c, cpb);
   int per8 = (max_blocks / 8) / ncb;
+  // (no more row blocks than the dataset has tiles: a small dataset would launch workgroups with nothing to do and
+  // the finalize kernel would add their zeros)
+  const int64_t tiles8 = ((n + kTileRows - 1) / kTileRows + 7) / 8;
+  if (per8 > tiles8) per8 = (int)tiles8;
   if (per8 < 1) per8 = 1;
   const int nrb = 8 * per8;
   // workspace: partials [nrb][c][d+2]
