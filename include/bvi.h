@@ -166,6 +166,11 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
  *                    double, from those pack-time sums after the reduction.  Log-density at f32 accuracy,
  *                    gradient error at the level of the exact-f32 kernel's, for residuals down to ~1/5000 of
  *                    the fitted values and columns whose mean is up to ~1000 times their spread.
+ *                    The format is meant for datasets of many tiles (the host layer packs from 16384 rows on): the
+ *                    padding rows of the last tile take part with the residual of a reference chain and are taken
+ *                    out again after the reduction, which costs a chain whose intercept lies far from its block's
+ *                    first chain up to 128 / n of the float precision of its (then very large) log-density -- 2e-5
+ *                    relative at n = 1, below 1e-7 from a few thousand rows on.
  * Padding rows are zero (BF16X3: n_pad = n rounded up to 64).  bvi_linreg_pack needs bvi_linreg_pack_scratch_bytes
  * of workspace (0 for BF16X3). */
 #define BVI_PACK_BF16X3 0
