@@ -1271,7 +1271,8 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
     part[1][grp][o] = sx;
     __syncthreads();
     if (grp == 0) {
-      for (int w = 1; w < kFinGroups; ++w) {
+#pragma unroll 4
+      for (int w = 1; w < kFinGroups; ++w) {      // (not unrolled all the way: 16 waves' worth of doubles in flight spill)
         s += part[0][w][o];
         sx += part[1][w][o];
       }
@@ -1316,9 +1317,11 @@ __global__ __launch_bounds__(64 * kFinGroups) void linreg_f16_finalize(
       const double cs = (double)hdr->colscale[f];
       double m[5];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        m[k] = part[k][0][f];
-        for (int w = 1; w < kFinGroups; ++w) m[k] += part[k][w][f];
+      for (int k = 0; k < 5; ++k) m[k] = part[k][0][f];
+#pragma unroll 2
+      for (int w = 1; w < kFinGroups; ++w) {      // (two waves' five sums at a time: all 80 at once spill)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) m[k] += part[k][w][f];
       }
       // kernel: r_k = y - b0_eff - xh.wk with wk = w - dw and b0_eff = b0 - db, G_k = sum xh r_k
       // (G'_f = t s_f G_k,f).  The true residual is r = r_k - (db + xr.w + xh.dw), hence
