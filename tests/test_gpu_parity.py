@@ -330,6 +330,35 @@ def test_linreg_f16_columns_far_off_centre(nat, ws, gpu_device, c):
     assert_grad_close(g, ref_g, term_scale=_linreg_term_scale(X, y, th))
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_linreg_f16_random_shapes(nat, ws, gpu_device, seed):
+    """Random feature counts (9 - 64), chain counts around every block boundary (1 ... 300), ragged row counts,
+    columns off-centre by up to 300 times their spread and six decades apart in scale, chains from 1e-3 to 0.3 of
+    the weights around the fit, now and then one chain thousands of times further out (its block then keeps one
+    scale and intercept per chain): value + gradient and value only against the float64 closed form."""
+    rng = np.random.default_rng(seed)
+    for _ in range(12):
+        d = int(rng.integers(9, 65)); c = int(rng.choice([1, 3, 16, 17, 33, 64, 65, 100, 129, 256, 257, 300]))
+        n = int(rng.choice([50, 127, 128, 129, 1000, 4097, 20000, 70001]))
+        off = rng.normal(size=d) * 10.0 ** rng.uniform(-1, 2.5)
+        X = (rng.normal(size=(n, d)) * 10.0 ** rng.uniform(-2, 2, d) + off).astype(np.float32)
+        w = rng.normal(size=d) / np.maximum(np.abs(X).max(0), 1e-3)
+        y = (rng.normal() * 5 + X.astype(np.float64) @ w + rng.normal(size=n) * 10.0 ** rng.uniform(-1, 0.5)).astype(np.float32)
+        spread = 10.0 ** rng.uniform(-3, -0.5)
+        th = np.concatenate([y.mean() - off @ w + spread * rng.normal(size=(c, 1)),
+                             w * (1 + spread * rng.normal(size=(c, d))), rng.uniform(0.5, 2.0, (c, 1))], -1).astype(np.float32)
+        if rng.random() < 0.3 and c > 2:
+            th[rng.integers(c), 1:1 + d] *= 3000.0
+        ref_lp, ref_g = cf.linreg(X, y, th)
+        Xd, yd, thd = dev(X, gpu_device), dev(y, gpu_device), dev(th, gpu_device)
+        pk = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+        lp, g = nat.linreg_packed_logp_grad(pk, n, d, thd, ws, fmt=nat.PACK_F16)
+        lpv, _ = nat.linreg_packed_logp_grad(pk, n, d, thd, ws, fmt=nat.PACK_F16, want_grad=False)
+        assert_logp_close(lp.cpu().numpy(), ref_lp)
+        assert_logp_close(lpv.cpu().numpy(), ref_lp)
+        assert_grad_close(g.cpu().numpy(), ref_g)
+
+
 def test_linreg_f16_pieces_edge_behaviour(nat, ws, gpu_device):
     rng = np.random.default_rng(3)
     X, y, th = _linreg_case(rng, 5000, 64, 130)
