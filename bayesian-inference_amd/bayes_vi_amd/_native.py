@@ -20,7 +20,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 107     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 108     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -78,6 +78,7 @@ def lib():
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_logp_rebase.argtypes = [i32, vp, i32, vp, vp, vp]
+        l.bvi_logp_rebase_shard.argtypes = [i32, vp, ctypes.c_double, vp, vp, vp]
         l.bvi_linreg_packed_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]
         l.bvi_linreg_pack_scratch_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
         l.bvi_linreg_pack.argtypes = [vp, vp, i64, i32, i32, vp, sz, vp, sz, vp]
@@ -117,7 +118,7 @@ def lib():
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
-                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads', 'bvi_advi_fullrank_sample',
+                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_logp_rebase_shard', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads', 'bvi_advi_fullrank_sample',
                      'bvi_advi_fullrank_grads',
                      'bvi_clip_adam_step'):
             getattr(l, name).restype = i32
@@ -171,8 +172,8 @@ def _ref_ptr(logp_ref):
     """Device address of the level the likelihood entry points subtract in double (one float64), or NULL."""
     if logp_ref is None:
         return None
-    if not (logp_ref.is_cuda and logp_ref.dtype == torch.float64 and logp_ref.numel() == 1):
-        raise BviError('logp_ref must be one float64 on the device')
+    if not (logp_ref.is_cuda and logp_ref.dtype == torch.float64 and logp_ref.numel() in (1, 2)):
+        raise BviError('logp_ref must be one float64 on the device (or the [own, total] pair of bvi_logp_rebase_shard)')
     return logp_ref.data_ptr()
 
 
@@ -181,6 +182,16 @@ def logp_rebase(lp, n_shards, logp_ref, lp_absolute=None):
     _check_f32_cuda(lp)
     check(lib().bvi_logp_rebase(lp.shape[0], _ptr(lp), int(n_shards), _ref_ptr(logp_ref), _ptr(lp_absolute), _stream()),
           'bvi_logp_rebase')
+
+
+def logp_rebase_shard(lp, share, levels, lp_absolute=None):
+    """bvi_logp_rebase_shard: lp -= m (its largest finite entry); levels[0] += m * share (this row shard's own level);
+    levels[1] += m (the level of the total over all shards); lp_absolute <- the absolute values."""
+    _check_f32_cuda(lp)
+    if not (levels.is_cuda and levels.dtype == torch.float64 and levels.numel() == 2 and levels.is_contiguous()):
+        raise BviError('levels must be two float64 on the device: [own level, total level]')
+    check(lib().bvi_logp_rebase_shard(lp.shape[0], _ptr(lp), float(share), levels.data_ptr(), _ptr(lp_absolute),
+                                      _stream()), 'bvi_logp_rebase_shard')
 
 
 def _outputs(theta, want_grad):

@@ -51,15 +51,20 @@ class ShardedLogLikelihood:
     def _call(self, theta, logp, grad):
         raise NotImplementedError
 
-    def logp_grad(self, theta, want_grad=True):
-        """theta[C, P] float32 (constrained) -> (logp[C], grad[C, P] or None), summed over ALL shards."""
+    def logp_grad(self, theta, want_grad=True, relative=False):
+        """theta[C, P] float32 (constrained) -> (logp[C], grad[C, P] or None), summed over ALL shards.
+        `relative=True` (the device samplers only) asks for log-likelihoods relative to the level the likelihood
+        keeps on the device (`FusedLogLikelihood.logp_ref`); every other caller gets absolute values."""
         theta = theta.contiguous()
         c = theta.shape[0]
         # one flat buffer so that the shard reduction is a single collective
         buf = torch.empty(c * (1 + (self.n_params if want_grad else 0)), dtype=torch.float32, device=theta.device)
         logp = buf[:c]
         grad = buf[c:].view(c, self.n_params) if want_grad else None
-        self._call(theta, logp, grad)
+        if relative:
+            self._call(theta, logp, grad, relative=True)
+        else:
+            self._call(theta, logp, grad)
         if self.sharded:
             # a gloo group cannot reduce device memory (it waits for ever): such a group -- a rehearsal of the
             # multi-rank path on fewer GPUs than ranks -- gets the buffer staged through the host
@@ -105,13 +110,14 @@ class FusedLogLikelihood(ShardedLogLikelihood):
             raise _native.BviError('the fused log-likelihood runs on MI355X only; got device %s' % device)
         _native.lib()
         self.ws = _native.Workspace(self.device)
-        # level (one float64 on the device) that the kernels subtract from every log-likelihood before rounding it
-        # to float; None = absolute values.  The samplers switch it on and keep it near the chains' current values
-        # (Posterior.rebase), so that the differences they decide on stay exact when |log-likelihood| ~ 1e7.
+        # level (one float64 on the device) that the kernels subtract from a log-likelihood before rounding it to
+        # float, for the calls that ask for it (`logp_grad(..., relative=True)`: the device samplers, which keep it
+        # near the chains' current values with Posterior.rebase so that the differences they decide on stay exact
+        # when |log-likelihood| ~ 1e7).  Calls without `relative` return absolute values whether a level exists or not.
         self.logp_ref = None
 
-    def _ref(self):
-        return None if self.logp_ref is None else self.logp_ref.data_ptr()
+    def _ref(self, relative):
+        return self.logp_ref.data_ptr() if relative and self.logp_ref is not None else None
 
 
 def _launch(fn, *args):
@@ -128,11 +134,11 @@ class NormalIID(FusedLogLikelihood):
         self.y = y.to(torch.float32).contiguous().reshape(-1)
         self.n = self.y.shape[0]
 
-    def _call(self, theta, logp, grad):
+    def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c))
         _launch(_native.lib().bvi_normal_iid_logp_grad, _native._ptr(self.y), self.n, _native._ptr(theta), c,
-                _native._ptr(logp), _native._ptr(grad), self._ref(), _native._ptr(buf), buf.numel(), _native._stream())
+                _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class LinearRegression(FusedLogLikelihood):
@@ -177,7 +183,7 @@ class LinearRegression(FusedLogLikelihood):
             return _native.PACK_F16
         return None
 
-    def _call(self, theta, logp, grad):
+    def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d))
         fmt = self.matrix_core_format(c)
@@ -188,11 +194,11 @@ class LinearRegression(FusedLogLikelihood):
                 self.packed = _native.linreg_pack(self.X, self.y, fmt=fmt)
                 self.packed_format = fmt
             _launch(_native.lib().bvi_linreg_packed_logp_grad, _native._ptr(self.packed), self.n, self.d,
-                    fmt, _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), self._ref(),
+                    fmt, _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), self._ref(relative),
                     _native._ptr(buf), buf.numel(), _native._stream())
             return
         _launch(_native.lib().bvi_linreg_logp_grad, _native._ptr(self.X), _native._ptr(self.y), self.n, self.d,
-                _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), self._ref(),
+                _native._ptr(theta), c, self.precision, _native._ptr(logp), _native._ptr(grad), self._ref(relative),
                 _native._ptr(buf), buf.numel(), _native._stream())
 
 
@@ -213,11 +219,11 @@ class GaussianMixture1D(FusedLogLikelihood):
         self.n, self.k = self.y.shape[0], int(k)
         self.n_params = 3 * self.k
 
-    def _call(self, theta, logp, grad):
+    def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, k=self.k))
         _launch(_native.lib().bvi_gmm1d_logp_grad, _native._ptr(self.y), self.n, self.k, _native._ptr(theta), c,
-                _native._ptr(logp), _native._ptr(grad), self._ref(), _native._ptr(buf), buf.numel(), _native._stream())
+                _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class GaussianMixtureFullCov(FusedLogLikelihood):
@@ -232,11 +238,11 @@ class GaussianMixtureFullCov(FusedLogLikelihood):
         self.k = int(k)
         self.n_params = self.k * (1 + self.d + self.d * self.d)
 
-    def _call(self, theta, logp, grad):
+    def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d, k=self.k))
         _launch(_native.lib().bvi_gmm_fullcov_logp_grad, _native._ptr(self.Y), self.n, self.d, self.k,
-                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(), _native._ptr(buf),
+                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf),
                 buf.numel(), _native._stream())
 
 
@@ -309,14 +315,32 @@ class Posterior:
     # (one float64; bvi_logp_rebase moves it to the chains' best current value after every transition), so what is
     # stored and subtracted stays small and exact; target_log_prob is reported absolute, as the reference does.
     def use_relative_log_prob(self):
+        """Give the likelihood a level: two float64 on the device, [this row shard's own level, the level of the
+        total over all shards].  Only calls that ask for it (`relative=True`) subtract it."""
         lik = self.likelihood
         if hasattr(lik, 'logp_ref') and lik.logp_ref is None and lik.device.type == 'cuda':
-            lik.logp_ref = torch.zeros(1, dtype=torch.float64, device=lik.device)
+            lik.logp_ref = torch.zeros(2, dtype=torch.float64, device=lik.device)
         return getattr(lik, 'logp_ref', None) is not None
 
-    def _shards(self):
-        lik = self.likelihood
-        return dist.get_world_size(lik.group) if lik.sharded else 1
+    def _share(self):
+        """This shard's part of the rows (1 without shards): the part of the total level its own level takes.  A
+        shard's log-likelihood is that part of the total up to O(sqrt(rows)), whatever the sizes of the shards."""
+        if getattr(self, '_row_share', None) is None:
+            lik = self.likelihood
+            share = 1.0
+            if lik.sharded:
+                inner = getattr(lik, 'inner', lik)
+                rows = getattr(inner, 'n', None)
+                world = dist.get_world_size(lik.group)
+                if rows is None:
+                    share = 1.0 / world
+                else:
+                    on_host = dist.get_backend(lik.group) == 'gloo'
+                    t = torch.tensor([float(rows)], dtype=torch.float64, device='cpu' if on_host else lik.device)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=lik.group)
+                    share = float(rows) / float(t[0])
+            self._row_share = share
+        return self._row_share
 
     def rebase(self, lp, lp_absolute=None):
         """After a transition: re-level the chains' stored log-densities `lp` in place (no-op without a level);
@@ -326,16 +350,16 @@ class Posterior:
             if lp_absolute is not None:
                 lp_absolute.copy_(lp)
             return
-        _native.logp_rebase(lp, self._shards(), ref, lp_absolute)
+        _native.logp_rebase_shard(lp, self._share(), ref, lp_absolute)
 
     def initial_log_prob_and_grad(self, z, want_grad=True):
         """First evaluation of a run: with a level in use, one pass finds it (the values of that pass are absolute
         floats, +-0.5 at |log pi| ~ 1e7), the level moves to the best chain, and a second pass returns values
         relative to it -- so that a chain which rejects its first proposals does not keep a rounded log-density."""
-        lp, g = self.unconstrained_log_prob_and_grad(z, want_grad)
+        lp, g = self.unconstrained_log_prob_and_grad(z, want_grad, relative=True)
         if getattr(self.likelihood, 'logp_ref', None) is not None:
             self.rebase(lp.contiguous())
-            lp, g = self.unconstrained_log_prob_and_grad(z, want_grad)
+            lp, g = self.unconstrained_log_prob_and_grad(z, want_grad, relative=True)
         return lp, g
 
     def state_log_prob(self, state):
@@ -345,7 +369,7 @@ class Posterior:
         ref = getattr(self.likelihood, 'logp_ref', None)
         if ref is None:
             return state['target_log_prob'].clone()
-        level = ref * float(self._shards())
+        level = ref[1]
         if 'relative_log_prob' in state:
             return (state['relative_log_prob'].double() + (state['log_prob_level'] - level)).float()
         return (state['target_log_prob'].double() - level).float()
@@ -356,14 +380,14 @@ class Posterior:
         if ref is None:
             return {'target_log_prob': lp}
         return {'target_log_prob': self.absolute(lp) if lp_absolute is None else lp_absolute,
-                'relative_log_prob': lp, 'log_prob_level': ref * float(self._shards())}
+                'relative_log_prob': lp, 'log_prob_level': ref[1].clone()}
 
     def absolute(self, lp):
         """Absolute log-densities for values expressed relative to the current level."""
         ref = getattr(self.likelihood, 'logp_ref', None)
         if ref is None:
             return lp
-        return (lp.double() + ref * float(self._shards())).float()
+        return (lp.double() + ref[1]).float()
 
     # ---- constrained space: the closure of mcmc.py:57-62 / vi.py:46-52 ----
     def log_prior(self, theta, want_grad=True):
@@ -381,11 +405,12 @@ class Posterior:
         return self.log_prob_and_grad(theta, want_grad=False)[0]
 
     # ---- unconstrained space: what TransformedTransitionKernel evaluates (mcmc.py:153-156) ----
-    def unconstrained_log_prob_and_grad(self, z, want_grad=True):
+    def unconstrained_log_prob_and_grad(self, z, want_grad=True, relative=False):
         """log pi(z) = log pi(f(z)) + fldj(z) and its gradient in unconstrained space, z[C, Pu]: what
         tfp.mcmc.TransformedTransitionKernel makes of the target closure (mcmc.py:153-156).  With built-in
         priors and bijectors on the GPU this is three launches -- bvi_constrain, the fused data pass,
-        bvi_posterior_assemble --; other models compose the same quantities from the bijector objects."""
+        bvi_posterior_assemble --; other models compose the same quantities from the bijector objects.
+        Values are absolute unless `relative` (device samplers: relative to the likelihood's level)."""
         blocks = self.device_blocks() if z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 else None
         if blocks is not None:
             lib, ptr, st = _native.lib(), _native._ptr, _native._stream()
@@ -393,7 +418,8 @@ class Posterior:
             c = z.shape[0]
             theta = torch.empty(c, self.n_constrained, dtype=torch.float32, device=z.device)
             _native.check(lib.bvi_constrain(blocks, len(blocks), c, ptr(z), ptr(theta), st), 'bvi_constrain')
-            ll, gl = self.likelihood.logp_grad(theta, want_grad)
+            ll, gl = self.likelihood.logp_grad(theta, want_grad, relative) if relative else \
+                self.likelihood.logp_grad(theta, want_grad)
             lp = torch.empty(c, dtype=torch.float32, device=z.device)
             gz = torch.empty_like(z) if want_grad else None
             _native.check(lib.bvi_posterior_assemble(blocks, len(blocks), c, ptr(z), ptr(theta), ptr(ll),

@@ -56,7 +56,7 @@ class DeviceHamiltonianMonteCarloKernel:
         _native.check(lib.bvi_leapfrog_pre(self.blocks, self.nb, c, eps, ptr(z), ptr(b['p']), ptr(g),
                                            ptr(b['theta']), st), 'bvi_leapfrog_pre')
         for i in range(self.num_leapfrog_steps):
-            ll, gl = lik.logp_grad(b['theta'], True)          # fused data pass (+ all-reduce over row shards)
+            ll, gl = lik.logp_grad(b['theta'], True, relative=True)          # fused data pass (+ all-reduce over row shards)
             # interior steps: the second half of this step and the first half of the next in one launch
             last = i + 1 == self.num_leapfrog_steps
             fn, name = (lib.bvi_leapfrog_post, 'bvi_leapfrog_post') if last else (lib.bvi_leapfrog_mid, 'bvi_leapfrog_mid')
@@ -406,7 +406,7 @@ class BatchedDeviceNoUTurnSamplerKernel:
                 _native.check(lib.bvi_leapfrog_pre_chainwise(self.blocks, self.nb, c, ptr(b['se']), ptr(b['q']),
                                                              ptr(b['p']), ptr(b['gq']), ptr(b['theta']), st),
                               'bvi_leapfrog_pre_chainwise')
-                ll, gl = lik.logp_grad(b['theta'], True)      # fused data pass (+ all-reduce over row shards)
+                ll, gl = lik.logp_grad(b['theta'], True, relative=True)      # fused data pass (+ all-reduce over row shards)
                 _native.check(lib.bvi_leapfrog_post_chainwise(self.blocks, self.nb, c, ptr(b['se']), ptr(b['q']),
                                                               ptr(b['p']), ptr(b['theta']), ptr(ll), ptr(gl),
                                                               ptr(b['lpq']), ptr(b['gq']), st),
@@ -479,7 +479,7 @@ class DeviceRandomWalkMetropolisKernel:
                                         ptr(b['g0']), ptr(b['lp0']), ptr(b['k0']), None, st), 'bvi_hmc_begin')
         _native.check(lib.bvi_leapfrog_pre(self.blocks, self.nb, c, self.scale, ptr(z), ptr(b['p']), ptr(g),
                                            ptr(b['theta']), st), 'bvi_leapfrog_pre')
-        ll, _ = self.posterior.likelihood.logp_grad(b['theta'], False)
+        ll, _ = self.posterior.likelihood.logp_grad(b['theta'], False, relative=True)
         _native.check(lib.bvi_posterior_assemble(self.blocks, self.nb, c, ptr(z), ptr(b['theta']), ptr(ll), None,
                                                  ptr(lp), None, st), 'bvi_posterior_assemble')
         _native.check(lib.bvi_hmc_end(c, pu, seed, step, None, ptr(z), ptr(g), ptr(lp), ptr(b['p']), ptr(b['z0']),

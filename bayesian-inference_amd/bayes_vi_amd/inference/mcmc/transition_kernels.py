@@ -6,15 +6,6 @@ from . import samplers
 from .stepsize_adaptation_kernels import StepSizeAdaptationKernel
 
 
-def _absolute_log_prob(target):
-    """The host (torch) kernels keep plain float log-densities.  A device kernel that ran on the same posterior before
-    may have left its likelihood returning values relative to a level (Posterior.use_relative_log_prob): switch that
-    off, so that what these kernels store and report is absolute."""
-    lik = getattr(getattr(target, '__self__', None), 'likelihood', None)
-    if lik is not None and getattr(lik, 'logp_ref', None) is not None:
-        lik.logp_ref = None
-
-
 class TransitionKernel:
     """Base class for Markov transition kernels (transition_kernels.py:12-38)."""
 
@@ -77,7 +68,6 @@ class HamiltonianMonteCarlo(TransitionKernel):
             if fam is not None:     # small dataset: whole transitions in one launch
                 return FusedHamiltonianMonteCarloKernel(post, fam, self.step_size, self.num_leapfrog_steps)
             return DeviceHamiltonianMonteCarloKernel(post, self.step_size, self.num_leapfrog_steps)
-        _absolute_log_prob(target)
         return samplers.HamiltonianMonteCarloKernel(target, self.step_size, self.num_leapfrog_steps)
 
 
@@ -112,7 +102,6 @@ class NoUTurnSampler(TransitionKernel):
             if post.device_blocks() is not None:    # any size: tree bookkeeping on the device, batched data passes
                 return BatchedDeviceNoUTurnSamplerKernel(post, self.step_size, self.max_tree_depth,
                                                          self.max_energy_diff)
-        _absolute_log_prob(target)
         return samplers.NoUTurnSamplerKernel(target, self.step_size, self.max_tree_depth, self.max_energy_diff,
                                              self.unrolled_leapfrog_steps)
 
@@ -138,5 +127,4 @@ class RandomWalkMetropolis(TransitionKernel):
                 return FusedRandomWalkMetropolisKernel(post, fam)
             if post.device_blocks() is not None:    # any size: propose / accept on the stream, no host sync
                 return DeviceRandomWalkMetropolisKernel(post)
-        _absolute_log_prob(target)
         return samplers.RandomWalkMetropolisKernel(target, new_state_fn=self.new_state_fn)

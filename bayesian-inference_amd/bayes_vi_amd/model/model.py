@@ -52,11 +52,11 @@ class _MappedLikelihood(ShardedLogLikelihood):
     def logp_ref(self, value):
         self.inner.logp_ref = value
 
-    def logp_grad(self, theta, want_grad=True):
+    def logp_grad(self, theta, want_grad=True, relative=False):
         if self.identity:
-            return self.inner.logp_grad(theta, want_grad)
+            return self.inner.logp_grad(theta, want_grad, relative)
         tk = theta.index_select(1, self.gather) * self.valid.to(theta.dtype)
-        lp, gk = self.inner.logp_grad(tk.contiguous(), want_grad)
+        lp, gk = self.inner.logp_grad(tk.contiguous(), want_grad, relative)
         if not want_grad:
             return lp, None
         g = torch.zeros_like(theta)

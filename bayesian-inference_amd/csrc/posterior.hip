@@ -350,15 +350,19 @@ __global__ __launch_bounds__(1024) void hmc_end_kernel(int C, int Pu, uint64_t s
   }
 }
 
-// Re-levels the stored log-densities of all chains: m = the largest finite lp[c]; lp[c] -= m; *ref += m / shards.
+// Re-levels the stored log-densities of all chains: m = the largest finite lp[c]; lp[c] -= m; *ref += m * share.
 // With ref handed to the likelihood entry points as logp_ref, every later evaluation comes out relative to the new
 // level, i.e. small wherever the chains are, and differences between a proposal and the current state keep float
 // precision however large the log-density itself is (at 10M rows |log pi| ~ 1e7, where floats are 1 apart).
-// lp_abs (optional) receives the absolute values, float(lp[c] + shards * ref), as they were before this call.
-__global__ __launch_bounds__(1024) void logp_rebase_kernel(int C, float* __restrict__ lp, int shards,
-                                                           double* __restrict__ ref, float* __restrict__ lp_abs) {
+// `share` is this row shard's part of the total level (1 / shards for equal shards, rows_local / rows_total in
+// general: a shard's log-likelihood is that part of the total up to O(sqrt(rows)) fluctuations, so its own
+// level stays next to its own values).  The total level is *total when given (it moves by m on every rank), else
+// *ref / share.  lp_abs (optional) receives the absolute values, float(lp[c] + total level), as they were before.
+__global__ __launch_bounds__(1024) void logp_rebase_kernel(int C, float* __restrict__ lp, double share,
+                                                           double* __restrict__ ref, double* __restrict__ total,
+                                                           float* __restrict__ lp_abs) {
   __shared__ float red[16];
-  const double level = *ref * (double)shards;
+  const double level = total ? *total : *ref / share;
   float m = -INFINITY;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float v = lp[c];
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(1024) void logp_rebase_kernel(int C, float* __restr
   }
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();                       // also: every thread has read *ref before thread 0 rewrites it
+  __syncthreads();                       // also: every thread has read the levels before thread 0 rewrites them
   m = red[0];
   for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
   if (!isfinite(m)) m = 0.f;             // no chain with a finite density: nothing to level
@@ -375,7 +379,10 @@ __global__ __launch_bounds__(1024) void logp_rebase_kernel(int C, float* __restr
     if (lp_abs) lp_abs[c] = (float)((double)v + level);
     lp[c] = v - m;
   }
-  if (threadIdx.x == 0) *ref += (double)m / (double)shards;
+  if (threadIdx.x == 0) {
+    *ref += (double)m * share;
+    if (total) *total += (double)m;
+  }
 }
 
 inline dim3 chain_grid(int C) { return dim3(bvi_ceil_div(C, 64)); }
@@ -524,7 +531,15 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
 int bvi_logp_rebase(int n_chains, float* lp, int n_shards, double* logp_ref, float* lp_absolute, void* stream) {
   if (!lp || !logp_ref || n_chains < 1 || n_shards < 1) return BVI_ERR_ARG;
   hipLaunchKernelGGL(logp_rebase_kernel, dim3(1), dim3(n_chains > 256 ? 1024 : 256), 0, (hipStream_t)stream, n_chains,
-                     lp, n_shards, logp_ref, lp_absolute);
+                     lp, 1.0 / (double)n_shards, logp_ref, (double*)nullptr, lp_absolute);
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
+int bvi_logp_rebase_shard(int n_chains, float* lp, double share, double* levels, float* lp_absolute, void* stream) {
+  if (!lp || !levels || n_chains < 1 || !(share > 0.0) || !(share <= 1.0)) return BVI_ERR_ARG;
+  hipLaunchKernelGGL(logp_rebase_kernel, dim3(1), dim3(n_chains > 256 ? 1024 : 256), 0, (hipStream_t)stream, n_chains,
+                     lp, share, levels, levels + 1, lp_absolute);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

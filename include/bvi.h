@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 107
+#define BVI_VERSION 108
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -256,6 +256,14 @@ int bvi_hmc_end(int n_chains, int n_unconstrained, uint64_t seed, uint64_t step,
  * transitions (after bvi_hmc_end / bvi_nuts_subtree_end), when lp holds the chains' current states only.  No
  * counterpart in the reference (TFP keeps float32 log-probs); allocates nothing, capturable in a HIP graph. */
 int bvi_logp_rebase(int n_chains, float* lp, int n_shards, double* logp_ref, float* lp_absolute, void* stream);
+
+/* The same for row shards of any sizes.  levels[0] is this shard's own level (the logp_ref of its likelihood calls),
+ * levels[1] the level of the total over all shards (identical on every rank); share = rows of this shard / rows of
+ * all shards.  m as above; lp[c] -= m; levels[0] += m * share; levels[1] += m; lp_absolute[c] = float(lp[c] +
+ * levels[1]) as before the call.  A shard's log-likelihood is its share of the total up to O(sqrt(rows))
+ * fluctuations, so each shard's outputs stay small whatever the split (with m / n_shards on unequal shards a
+ * 60 / 40 split of 1e7 would leave 1e6 in each shard's floats).  No counterpart in the reference. */
+int bvi_logp_rebase_shard(int n_chains, float* lp, double share, double* levels, float* lp_absolute, void* stream);
 
 /* The two leapfrog halves with one signed step size per chain (step_sizes[C]; 0 leaves a chain untouched):
  * what the No-U-Turn sampler needs, whose chains integrate forwards or backwards in time and stop at

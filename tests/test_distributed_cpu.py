@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -98,6 +99,51 @@ def test_row_sharded_posterior_world2(tmp_path):
     k = samplers.HamiltonianMonteCarloKernel(post.unconstrained_log_prob_and_grad, step_size=0.005, num_leapfrog_steps=3)
     zs, _ = samplers.sample_chain(k, z, 5, 2, generator=torch.Generator().manual_seed(123))
     np.testing.assert_allclose(res['zs'].numpy(), zs.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_row_sharded_posterior_world8_rows_not_divisible(tmp_path):
+    """Eight ranks on 1001 rows (one shard of 126 rows, seven of 125): the all-reduce and the fixed-order all-gather variant
+    (both run inside `_worker`, which also checks that every rank ends with the same bits and that the replicated
+    HMC chains stay identical) give the unsharded posterior; priors counted once."""
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker, args=(8, port, out), nprocs=8, join=True)
+    res = torch.load(out)
+    X, y, z = make_data()
+    assert res['rows'] in (N // 8, N // 8 + 1)          # contiguous blocks [N r / 8, N (r + 1) / 8)
+    post = make_posterior(X, y, None)
+    lp, g = post.unconstrained_log_prob_and_grad(z)
+    np.testing.assert_allclose(res['lp'].numpy(), lp.numpy(), rtol=2e-6)
+    np.testing.assert_allclose(res['g'].numpy(), g.numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(res['lpv'].numpy(), lp.numpy(), rtol=2e-6)
+    k = samplers.HamiltonianMonteCarloKernel(post.unconstrained_log_prob_and_grad, step_size=0.005, num_leapfrog_steps=3)
+    zs, _ = samplers.sample_chain(k, z, 5, 2, generator=torch.Generator().manual_seed(123))
+    np.testing.assert_allclose(res['zs'].numpy(), zs.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_shard_levels_follow_row_shares():
+    """The arithmetic of bvi_logp_rebase_shard (include/bvi.h) restated on the host for eight shards of unequal sizes:
+    every shard's level moves by its share of the rows, the shares sum to one, so the shard levels always add up to the
+    total level, and a shard whose log-likelihood is its share of the total keeps relative values of O(fluctuation)."""
+    rows = np.array([126, 125, 125, 125, 125, 125, 125, 125], np.float64) * 1000
+    share = rows / rows.sum()
+    assert share.sum() == pytest.approx(1.0, abs=1e-15)
+    rng = np.random.default_rng(0)
+    own, total = np.zeros(8), 0.0
+    per_row = -1.4
+    for step in range(50):
+        # the chains' best total log-likelihood drifts by a few units per transition; each shard holds its share
+        # of it plus a fluctuation of the size of sqrt(rows)
+        best_total = per_row * rows.sum() + 3.0 * step + rng.normal()
+        shard_ll = best_total * share + rng.normal(size=8) * np.sqrt(rows)
+        shard_ll += (best_total - shard_ll.sum()) / 8
+        rel = np.float32(shard_ll - own)                     # what each shard's kernel returns (float)
+        m = np.float32(rel.astype(np.float64).sum())         # the all-reduced relative value of the best chain
+        own += float(m) * share; total += float(m)           # bvi_logp_rebase_shard on every rank
+        assert own.sum() == pytest.approx(total, rel=1e-14)
+        if step:
+            assert np.abs(rel).max() < 5 * np.sqrt(rows.max()) + 10
+    assert total == pytest.approx(best_total, abs=1.0)
 
 
 def _fit_worker(rank, world, port, out):

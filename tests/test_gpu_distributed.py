@@ -118,3 +118,29 @@ def test_two_ranks_on_one_gpu_stay_replicated_and_match_the_unsharded_run(gpu_de
     assert torch.equal(r0['acc_h'], ref['acc_h']) and torch.equal(r0['leaps'], ref['leaps'])
     np.testing.assert_allclose(r0['zs_h'].numpy(), ref['zs_h'].numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(r0['zn'].numpy(), ref['zn'].numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_rehearsal(gpu_device):
+    """`python bench.py --gpus 2` started without a launcher, as the round-end driver may start it: bench.py itself
+    spawns torch.distributed.run in a child process, the two ranks share this box's one GPU (BVI_BENCH_REHEARSAL=1:
+    gloo instead of RCCL, which refuses two ranks on one device), each packs and streams its row shard, every step
+    reduces the [C, 1+P] partial sums, and rank 0 prints exactly one result line."""
+    import json
+    import subprocess
+    env = dict(os.environ, BVI_BENCH_REHEARSAL='1', MASTER_ADDR='127.0.0.1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--rows', '400001',
+                           '--chains', '256', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=280)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_world'] == 2 and out['collective_backend'] == 'gloo'
+    assert out['finite'] is True and out['allreduce_ms'] is not None and out['allreduce_ms'] > 0
+    assert out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'strong'
+    assert out['config']['rows'] == 400001 and out['config']['rows_per_gpu'] == 200001      # rank 0 takes the odd row
+    assert out['value'] > 0 and out['roofline']['kernel_ms'] > 0
+    assert 'cpu_baseline' not in out and 'parity_at_bench_point' not in out                  # rank-0, one-GPU legs only

@@ -162,6 +162,41 @@ def test_regression_rwm_and_hmc(bvi):
     assert rwm.samples[1].cpu().numpy().mean() == pytest.approx(ols[1], abs=0.15)
 
 
+def test_public_log_prob_stays_absolute_after_a_device_sampler_ran(bvi, gpu_device):
+    """The device samplers work on log-densities relative to a level they keep on the device; `MCMC.target_log_prob`
+    (the closure of mcmc.py:57-62), `Posterior.log_prob` and `unconstrained_log_prob_and_grad` on the same -- cached --
+    posterior must return the same absolute values before and after such a run, for every device kernel."""
+    rng = np.random.default_rng(21)
+    n, d = 70_000, 8             # beyond the rows the whole-transition kernels take (those keep absolute floats)
+    X = rng.normal(size=(n, d)).astype(np.float32); w = rng.normal(size=d)
+    yy = (0.5 + X @ w + rng.normal(size=n)).astype(np.float32)
+    df = pd.DataFrame({**{'f%d' % i: X[:, i] for i in range(d)}, 'y': yy})
+    ds = bvi.make_dataset_from_df(df, ['y'], ['f%d' % i for i in range(d)], format_features_as='tensor')
+    priors = collections.OrderedDict(b=bvi.tfd.Normal(0., 10.), w=bvi.tfd.Normal(torch.zeros(d), 10.),
+                                     scale=bvi.tfd.HalfNormal(10.))
+    model = bvi.Model(priors, lambda b, w, scale, features: bvi.tfd.Normal(
+        loc=b + bvi.symbolic.matvec(features, w), scale=scale))
+    state = [torch.tensor([0.4, 0.6]), torch.tensor(np.stack([w, w + 0.01]), dtype=torch.float32), torch.tensor([1.0, 1.1])]
+    z = torch.tensor(rng.normal(0, 0.1, (3, d + 2)), dtype=torch.float32, device=gpu_device)
+    spec = cf.linreg_model(X, yy)
+    ref = spec.log_post_constrained(np.concatenate([s.reshape(2, -1).numpy() for s in state], -1))[0]
+    assert abs(ref).min() > 5e4                     # a level that leaked would show as an error of this size
+    for kernel in (bvi.HamiltonianMonteCarlo(step_size=1e-3, num_leapfrog_steps=3),
+                   bvi.NoUTurnSampler(step_size=1e-3, max_tree_depth=3), bvi.RandomWalkMetropolis()):
+        mcmc = bvi.MCMC(model, ds, kernel)
+        before = mcmc.target_log_prob(state).cpu().numpy()
+        before_u = mcmc.posterior.unconstrained_log_prob_and_grad(z)[0].cpu().numpy()
+        assert_logp_close(before, ref)
+        res = mcmc.fit(num_chains=4, num_samples=5, num_burnin_steps=5, progress_bar=False, seed=1)
+        assert mcmc.posterior.likelihood.logp_ref is not None      # a device kernel ran and kept a level
+        np.testing.assert_array_equal(mcmc.target_log_prob(state).cpu().numpy(), before)
+        np.testing.assert_array_equal(mcmc.posterior.unconstrained_log_prob_and_grad(z)[0].cpu().numpy(), before_u)
+        # and what the run itself reported is absolute as well
+        tl = res.trace['target_log_prob'] if 'target_log_prob' in res.trace else None
+        if tl is not None:
+            assert float(tl.abs().min()) > 5e4
+
+
 def test_vi_meanfield_advi_and_hnf(bvi):
     """README.md:264-279 (mean-field ADVI) and :626-637 (Hamiltonian normalizing flow)."""
     rng = np.random.default_rng(3)

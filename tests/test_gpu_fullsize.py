@@ -222,7 +222,10 @@ def test_device_hmc_keeps_relative_log_densities_at_10m_rows(regression_10m, gpu
         assert float((st['target_log_prob'].double() - ref).abs().max()) <= 2.0      # absolute: float spacing
         assert torch.equal(tr['target_log_prob'], st['target_log_prob'])
     assert accepted > 0
-    lik.logp_ref = None
+    # the level is the samplers' business only: every other evaluation of the same posterior stays absolute
+    lp_abs, _ = post.unconstrained_log_prob_and_grad(z)
+    assert float((lp_abs.double() - ref).abs().max()) <= 2.0
+    assert float(post.log_prob(theta).double().sub(ref - fldj).abs().max()) <= 2.0
 
 
 def test_regression_10m_row_shards_add(nat, ws, regression_10m):

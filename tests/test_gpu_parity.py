@@ -589,3 +589,50 @@ def test_logp_rebase_and_reference_level(nat, ws, gpu_device):
     assert torch.equal(g_abs, g_rel)
     assert float((lp_rel.double() + level - lp_abs.double()).abs().max()) <= 0.5 * 2.0 ** -5   # half a float step at 3.7e5
     assert abs(float(lp_rel[0])) <= 0.02
+
+
+def test_logp_rebase_shard_uneven_row_shards_keep_differences_exact(nat, ws, gpu_device):
+    """bvi_logp_rebase_shard on two row shards of very different sizes (70 % / 30 % of 3M rows): every shard's level
+    moves by its share of the rows, so each shard's own outputs stay small (with an equal split of the level the
+    smaller shard's floats would sit at ~0.2 x the total, 1e6, where they are 0.06 apart), the total level is the
+    same on both shards, and differences between chains agree with float64 to 1e-2."""
+    g = torch.Generator(device=gpu_device); g.manual_seed(12)
+    n = 3_000_000
+    y = torch.empty(n, device=gpu_device).normal_(2.0, 1.5, generator=g)
+    cut = int(0.7 * n) // 4 * 4
+    th = torch.tensor([[2.0, 1.5], [2.0005, 1.5004], [1.9996, 1.4997], [2.001, 1.499]], device=gpu_device)
+    th2 = th + torch.tensor([3e-4, -2e-4], device=gpu_device)
+    shards = [(y[:cut], cut / n), (y[cut:].clone(), (n - cut) / n)]
+    levels = [torch.zeros(2, dtype=torch.float64, device=gpu_device) for _ in shards]
+
+    def total(theta, relative):
+        parts = [nat.normal_iid_logp_grad(ys, theta, ws, logp_ref=lv if relative else None)[0]
+                 for (ys, _), lv in zip(shards, levels)]
+        return parts[0] + parts[1], parts
+
+    lp, _ = total(th, False)                        # bootstrap: absolute pass, then the level moves to the best chain
+    for (ys, share), lv in zip(shards, levels):
+        nat.logp_rebase_shard(lp.clone(), share, lv)
+    assert float(levels[0][1]) == float(levels[1][1]) == float(lp.max())
+    assert float(levels[0][0]) == pytest.approx(float(lp.max()) * cut / n, rel=1e-12)
+    lp, parts = total(th, True)
+    assert all(float(p.abs().max()) < 5e3 for p in parts)         # each shard's own floats are small: O(sqrt(rows))
+    # a transition's worth of movement, re-levelled, evaluated again
+    lp2, _ = total(th2, True)
+    absolute = torch.empty_like(lp2)
+    for (ys, share), lv in zip(shards, levels):
+        nat.logp_rebase_shard(lp2.clone(), share, lv, absolute)
+    lp3, parts3 = total(th2, True)
+    assert float(lp3.max()) == pytest.approx(0.0, abs=2e-3)
+    assert all(float(p.abs().max()) < 5e3 for p in parts3)
+    y64 = y.double()
+
+    def ref64(theta):
+        t = theta.double()
+        r = (y64[None, :] - t[:, :1]) / t[:, 1:]
+        return (-0.5 * r * r).sum(-1) - n * torch.log(t[:, 1]) - 0.5 * n * math.log(2 * math.pi)
+    r3 = ref64(th2)
+    d = lp3.double() - (r3 - r3.max())
+    assert float((d - d.mean()).abs().max()) <= 1e-2, float((d - d.mean()).abs().max())
+    assert float((absolute.double() - r3).abs().max()) <= 0.5            # absolute floats: spacing 0.25 at 5e6
+    assert float(levels[0][1]) == float(levels[1][1])

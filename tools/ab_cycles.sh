@@ -1,8 +1,8 @@
 #!/bin/bash
-# cycles (GRBM_GUI_ACTIVE / 8 XCDs) and duration of the regression kernel for every build under tools/ab/ and the in-tree one:
+# cycles (GRBM_GUI_ACTIVE / 8 XCDs) and duration of the regression kernel for every build under tools/abrun/ and the in-tree one:
 # separates what a change does to the cycle count from what the chip's clock management does to the time
 export TMPDIR=/tmp
-for l in bayesian-inference_amd/lib/libbvi_hip.so tools/ab/*.so; do
+for l in bayesian-inference_amd/lib/libbvi_hip.so tools/abrun/*.so; do
   out=gpurun_out/abc/$(basename $l .so); rm -rf $out; mkdir -p $out
   timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o p -- python3 tools/kbench.py --f16 --reps 6 --lib $l > $out/log.txt 2>&1 || { echo "$l failed"; exit 1; }
   python3 - $out $l <<'PY'

@@ -50,9 +50,10 @@ for _ in range(a.reps):
 ts.sort()
 med = ts[len(ts) // 2]
 fl = 4.0 * a.chains * a.rows * a.d
-print('packed=%s f16=%s ' % (a.packed, a.f16), end='')
-print('prec=%s rows=%d chains=%d: median %.3f ms  min %.3f  -> %.1f alg TFLOP/s, %.1f K grad-evals/s'
-      % (a.prec, a.rows, a.chains, med, ts[0], fl / med / 1e9, a.chains / med), flush=True)
+label = 'f16 plane (auto)' if a.f16 else ('%s, packed bf16 pieces' % a.prec if a.packed else a.prec)
+print('kernel=%s%s rows=%d chains=%d: median %.3f ms  min %.3f  -> %.1f alg TFLOP/s, %.1f K grad-evals/s'
+      % (label, ' value-only' if a.f16 and a.value_only else '', a.rows, a.chains, med, ts[0], fl / med / 1e9,
+         a.chains / med), flush=True)
 if a.check:
     lp2, gr2 = nat.linreg_logp_grad(X, y, th[:64].contiguous(), ws, precision=1)
     e1 = ((lp[:64] - lp2).abs() / lp2.abs()).max().item()
