@@ -445,6 +445,10 @@ class _TargetLogProbFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, theta, posterior):
         lp, g = posterior.log_prob_and_grad(theta.detach(), want_grad=True)
+        # a sample counts only if its log density AND its whole gradient are finite (a scale underflowing towards 0
+        # gives log pi = -1e38 with d log pi = -inf): such a sample reports -inf, so that the finite-mask of
+        # vi.py:55-58 drops it from loss and gradient alike instead of turning every variable into NaN
+        lp = torch.where(torch.isfinite(g).all(-1), lp, torch.full_like(lp, float('-inf')))
         ctx.save_for_backward(g)
         return lp
 

@@ -36,6 +36,27 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return t;
 }
 
+// Which samples count.  The reference drops the samples whose discrepancy is not finite before taking the mean
+// (vi.py:55-58); a sample whose log density is finite while an entry of its gradient is not (a scale underflowing
+// towards 0: log pi = -1e38, d log pi / d z = -inf) would pass that test and put NaN into the variables for good.
+// One predicate for every block of these kernels -- loss and gradients average over the same samples --:
+// log density finite and every entry of the sample's gradient finite.  Kept in LDS (one byte per sample) when the
+// samples fit, recomputed per use otherwise.
+constexpr int VI_MAX_FLAGS = 16384;
+__device__ __forceinline__ bool vi_sample_counts(const float* __restrict__ lp, const float* __restrict__ gz, int Pu,
+                                                 int s) {
+  bool ok = isfinite(lp[s]);
+  for (int k = 0; k < Pu; ++k) ok = ok && isfinite(gz[(int64_t)s * Pu + k]);
+  return ok;
+}
+__device__ __forceinline__ void vi_fill_flags(unsigned char* flags, int S, const float* __restrict__ lp,
+                                              const float* __restrict__ gz, int Pu) {
+  if (S <= VI_MAX_FLAGS)
+    for (int s = threadIdx.x; s < S; s += blockDim.x) flags[s] = vi_sample_counts(lp, gz, Pu, s) ? 1 : 0;
+  __syncthreads();
+}
+#define VI_COUNTS(s) (S <= VI_MAX_FLAGS ? flags[s] != 0 : vi_sample_counts(lp, gz, Pu, s))
+
 // block j < Pu: the two gradient entries of parameter j; block Pu: the loss.  Sums over the samples in double, in a
 // fixed order.
 __global__ __launch_bounds__(256) void advi_grads_kernel(int S, int Pu, const float* __restrict__ lp,
@@ -44,11 +65,13 @@ __global__ __launch_bounds__(256) void advi_grads_kernel(int S, int Pu, const fl
                                                          const float* __restrict__ raw, float* __restrict__ loss,
                                                          float* __restrict__ g_loc, float* __restrict__ g_raw) {
   __shared__ double red[4];
+  __shared__ unsigned char flags[VI_MAX_FLAGS];
   const int j = blockIdx.x;
   double nf = 0.0, a = 0.0, b = 0.0;
+  vi_fill_flags(flags, S, lp, gz, Pu);
   if (j < Pu) {
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      const bool fin = isfinite(lp[s]);
+      const bool fin = VI_COUNTS(s);
       const float g = fin ? gz[(int64_t)s * Pu + j] : 0.f;
       nf += fin ? 1.0 : 0.0;
       a += (double)g;
@@ -69,7 +92,7 @@ __global__ __launch_bounds__(256) void advi_grads_kernel(int S, int Pu, const fl
       for (int k = 0; k < Pu; ++k) { const double e = (double)eps[(int64_t)s * Pu + k]; e2 += e * e; }
       const double logq = -0.5 * e2 - 0.5 * Pu * BVI_LN2PI_D - lsig;
       const double d = -((double)lp[s] - logq);
-      const bool fin = isfinite(d);
+      const bool fin = VI_COUNTS(s) && isfinite(d);
       nf += fin ? 1.0 : 0.0;
       a += fin ? d : 0.0;
     }
@@ -106,11 +129,13 @@ __global__ __launch_bounds__(256) void advi_fullrank_grads_kernel(int S, int Pu,
                                                                   float* __restrict__ g_raw) {
   __shared__ double red[4];
   __shared__ double part[4][64];
+  __shared__ unsigned char flags[VI_MAX_FLAGS];
   const int i = blockIdx.x;
+  vi_fill_flags(flags, S, lp, gz, Pu);
   if (i < Pu) {
     double nf = 0.0, a = 0.0;
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      const bool fin = isfinite(lp[s]);
+      const bool fin = VI_COUNTS(s);
       nf += fin ? 1.0 : 0.0;
       a += fin ? (double)gz[(int64_t)s * Pu + i] : 0.0;
     }
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(256) void advi_fullrank_grads_kernel(int S, int Pu,
       double acc = 0.0;
       if (j <= i)
         for (int s = slice; s < S; s += 4)
-          if (isfinite(lp[s])) acc += (double)gz[(int64_t)s * Pu + i] * (double)eps[(int64_t)s * Pu + j];
+          if (VI_COUNTS(s)) acc += (double)gz[(int64_t)s * Pu + i] * (double)eps[(int64_t)s * Pu + j];
       __syncthreads();
       part[slice][jl] = acc;
       __syncthreads();
@@ -147,7 +172,7 @@ __global__ __launch_bounds__(256) void advi_fullrank_grads_kernel(int S, int Pu,
       for (int k = 0; k < Pu; ++k) { const double e = (double)eps[(int64_t)s * Pu + k]; e2 += e * e; }
       const double logq = -0.5 * e2 - 0.5 * Pu * BVI_LN2PI_D - lsig;
       const double d = -((double)lp[s] - logq);
-      const bool fin = isfinite(d);
+      const bool fin = VI_COUNTS(s) && isfinite(d);
       nf += fin ? 1.0 : 0.0;
       a += fin ? d : 0.0;
     }

@@ -25,6 +25,12 @@ def run_oracle(case):
         return cf.normal_iid(np.asarray(case['y'], np.float32), th)
     if case['family'] == 'linreg':
         return cf.linreg(np.asarray(case['X'], np.float32), np.asarray(case['y'], np.float32), th)
+    if case['family'] == 'gmm_fullcov':
+        k, d = case['k'], case['d']
+        c = th.shape[0]
+        w, mu, L = th[:, :k], th[:, k:k + k * d].reshape(c, k, d), th[:, k + k * d:].reshape(c, k, d, d)
+        lp, (gw, gmu, gL) = cf.gmm_fullcov(np.asarray(case['Y'], np.float32), w, mu, L)
+        return lp, np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
     return cf.gmm1d(np.asarray(case['y'], np.float32), th, case['k'])
 
 
@@ -35,8 +41,40 @@ def test_oracle_reproduces_golden():
         np.testing.assert_allclose(g, case['grad'], rtol=1e-10, atol=1e-10)
 
 
+def test_golden_covers_every_likelihood_family():
+    assert {c['family'] for c in load_cases()} == {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov'}
+
+
+def test_oracle_reproduces_golden_advi_step():
+    """tests/golden/advi_step_small.json: one whole `optimizer_step` of vi.py:64-73 with the mean-field surrogate --
+    draws, log densities, loss over the finite samples, raw and clipped gradients, Adam update."""
+    from oracle import elbo
+    with open(os.path.join(ROOT, 'tests', 'golden', 'advi_step_small.json')) as f:
+        gold = json.load(f)
+    spec = cf.linreg_model(np.asarray(gold['X'], np.float32), np.asarray(gold['y'], np.float32))
+    params = {'loc': np.asarray(gold['loc']), 'raw_scale': np.asarray(gold['raw_scale'])}
+    eps = np.asarray(gold['eps'])
+    with np.errstate(all='ignore'):
+        loss, grads, aux = elbo.advi_loss_and_grads(spec, params, eps, True)
+    fin = np.asarray(gold['finite'])
+    assert fin.tolist() == aux['finite'].tolist() and not fin.all()
+    np.testing.assert_allclose(aux['z'], gold['z'], rtol=1e-13)
+    np.testing.assert_allclose(aux['logq'][fin], np.asarray(gold['logq'])[fin], rtol=1e-12)
+    assert loss == gold['loss'] or abs(loss - gold['loss']) < 1e-10
+    opt = elbo.Adam(params, learning_rate=gold['learning_rate'])
+    with np.errstate(all='ignore'):
+        l2, clipped, new = elbo.advi_step(spec, params, eps, opt, True)
+    for k in ('loc', 'raw_scale'):
+        np.testing.assert_allclose(grads[k], gold['grad'][k], rtol=1e-10)
+        np.testing.assert_allclose(clipped[k], gold['clipped'][k], rtol=1e-10)
+        np.testing.assert_allclose(new[k], gold['after_adam'][k], rtol=1e-12)
+        assert np.sqrt((np.asarray(gold['clipped'][k]) ** 2).sum()) <= 1.0 + 1e-12        # vi.py:70
+
+
 def test_restated_torch_reproduces_golden():
     for case in load_cases():
+        if case['family'] == 'gmm_fullcov':
+            continue                     # the restated torch path covers the three families it is timed on
         th = torch.tensor(case['theta'], dtype=torch.float32)
         y = torch.tensor(case['y'], dtype=torch.float32)
         if case['family'] == 'normal_iid':

@@ -35,8 +35,16 @@ def dev(a, device):
 def test_golden_vectors(nat, ws, gpu_device):
     with open(os.path.join(ROOT, 'tests', 'golden', 'hotpath_small.json')) as f:
         cases = json.load(f)['cases']
+    assert {c['family'] for c in cases} == {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov'}
     for case in cases:
-        th = dev(case['theta'], gpu_device); y = dev(case['y'], gpu_device)
+        th = dev(case['theta'], gpu_device)
+        if case['family'] == 'gmm_fullcov':
+            lp, g = nat.gmm_fullcov_logp_grad(dev(case['Y'], gpu_device), th, case['k'], ws)
+            assert_logp_close(lp.cpu().numpy(), case['logp'])
+            assert_grad_close(g.cpu().numpy(), case['grad'], term_scale=np.full_like(np.asarray(case['grad']),
+                                                                                      3.0 * len(case['Y'])))
+            continue
+        y = dev(case['y'], gpu_device)
         if case['family'] == 'normal_iid':
             lp, g = nat.normal_iid_logp_grad(y, th, ws)
         elif case['family'] == 'linreg':

@@ -9,6 +9,7 @@ parameters are compared on the size of the update, lr: an Adam step is lr x a ra
 relative gradient error e moves it by ~lr e.
 """
 import collections
+import math
 
 import numpy as np
 import pytest
@@ -290,6 +291,44 @@ def test_non_finite_samples_are_dropped_on_the_device(bvi, gpu_device):
 
 
 @pytest.mark.parametrize('mean_field', [True, False])
+def test_sample_with_finite_density_and_non_finite_gradient_is_dropped(bvi, gpu_device, mean_field):
+    """A draw whose scale lands at ~1e-13 has a finite float32 log density (-1e29) but a gradient entry that
+    overflows (r^2 / scale^3 ~ 1e42).  vi.py:55-58 looks at the density only; here such a sample leaves loss and
+    gradients together, on the device step and on the autograd path alike: both equal the oracle's step over the
+    other samples, and the variables stay finite."""
+    d, s = 3, 8
+    model, ds, spec, _ = regression(bvi, gpu_device, 2_000, d, seed=73)
+    for fused in (True, False):
+        torch.manual_seed(5)
+        vi = bvi.VI(model, ds, bvi.ADVI(model, mean_field=mean_field))
+        vi.fused_advi = fused
+        sur = vi.surrogate_posterior
+        scale_var = sur.raw_scale if mean_field else sur.raw_tril
+        prm = advi_params(sur)
+        eps = f32_noise(np.random.default_rng(74), (s, spec.pu))
+        # solve for the noise that puts the unconstrained scale coordinate of draw 5 at log(1e-13)
+        if mean_field:
+            eps[5, -1] = (math.log(1e-13) - prm['loc'][-1]) / elbo.softplus(prm['raw_scale'][-1])
+        else:
+            L = elbo.advi_scale_tril(prm['raw_tril'])
+            eps[5, -1] = (math.log(1e-13) - prm['loc'][-1] - L[-1, :-1] @ eps[5, :-1].astype(np.float64)) / L[-1, -1]
+        inject(sur, [eps], gpu_device)
+        params = [p for p in sur.parameters() if p.requires_grad]
+        opt = bvi.Adam(learning_rate=0.05).bind(params)
+        assert vi._fused_advi_eligible(opt) == fused
+        loss = float(vi._step(opt, params, s))
+        keep = np.arange(s) != 5
+        ref_loss, ref_grads, aux = elbo.advi_loss_and_grads(spec, prm, eps[keep], mean_field)
+        assert aux['finite'].all() and np.isfinite(ref_loss)
+        ref_loc = elbo.clip_by_norm(ref_grads['loc'])
+        ref_scale = elbo.clip_by_norm(ref_grads['raw_scale' if mean_field else 'raw_tril'])
+        assert loss == pytest.approx(ref_loss, rel=RTOL)
+        assert_grad_close(sur.loc.grad.cpu().numpy()[None], ref_loc[None])
+        assert_grad_close(scale_var.grad.cpu().numpy().reshape(1, -1), ref_scale.reshape(1, -1))
+        assert bool(torch.isfinite(sur.loc).all()) and bool(torch.isfinite(scale_var).all())
+
+
+@pytest.mark.parametrize('mean_field', [True, False])
 def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device, mean_field):
     """Mean-field and full-rank ADVI on a model with the built-in priors / bijectors take the step without autograd (sample,
     data pass, closed-form ELBO gradients, clip + Adam in device kernels).  Same loss, clipped gradients, Adam
@@ -337,3 +376,57 @@ def test_fused_advi_step_equals_the_autograd_step(bvi, gpu_device, mean_field):
     assert np.isfinite(fits[True][0]).all() and fits[True][0][-1] < fits[True][0][0]
     np.testing.assert_allclose(fits[True][0], fits[False][0], rtol=1e-5)
     assert float((fits[True][1] - fits[False][1]).abs().max()) <= 1e-5
+
+
+def test_golden_advi_step_through_the_c_abi(gpu_device):
+    """tests/golden/advi_step_small.json (frozen oracle numbers): one mean-field ADVI optimisation step driven
+    entry point by entry point through the C ABI -- bvi_advi_meanfield_sample, bvi_constrain, bvi_linreg_logp_grad,
+    bvi_posterior_assemble, bvi_advi_meanfield_grads, bvi_clip_adam_step per variable (vi.py:60-75, 109-116).  One of
+    the six samples has a log density that is not finite and must drop out of loss and gradients (vi.py:55-58)."""
+    import json
+    import os
+    from bayes_vi_amd import _native as nat
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'tests', 'golden', 'advi_step_small.json')) as f:
+        gold = json.load(f)
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=gpu_device).contiguous()
+    X, y, eps = t(gold['X']), t(gold['y']), t(gold['eps'])
+    loc, raw = t(gold['loc']), t(gold['raw_scale'])
+    s, pu = eps.shape
+    d = X.shape[1]
+    blocks = nat.make_blocks([(nat.BIJ_IDENTITY, 1, nat.PRIOR_NORMAL, 0.0, 10.0),
+                              (nat.BIJ_IDENTITY, d, nat.PRIOR_NORMAL, 0.0, 10.0),
+                              (nat.BIJ_SOFTPLUS, 1, nat.PRIOR_HALFNORMAL, 10.0, 0.0)])
+    lib, ptr, st = nat.lib(), nat._ptr, nat._stream()
+    f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=gpu_device)
+    z, theta, lp, gz = f(s, pu), f(s, pu), f(s), f(s, pu)
+    nat.check(lib.bvi_advi_meanfield_sample(s, pu, ptr(eps), ptr(loc), ptr(raw), ptr(z), st), 'sample')
+    np.testing.assert_allclose(z.cpu().numpy(), gold['z'], rtol=2e-6, atol=1e-6)
+    nat.check(lib.bvi_constrain(blocks, 3, s, ptr(z), ptr(theta), st), 'constrain')
+    ll, gl = nat.linreg_logp_grad(X, y, theta, nat.Workspace(gpu_device))
+    nat.check(lib.bvi_posterior_assemble(blocks, 3, s, ptr(z), ptr(theta), ptr(ll), ptr(gl), ptr(lp), ptr(gz), st),
+              'assemble')
+    fin = np.asarray(gold['finite'])
+    got_lp = lp.cpu().numpy()
+    assert np.isfinite(got_lp).tolist() == fin.tolist()
+    assert_logp_close(got_lp[fin], np.asarray(gold['log_post_unconstrained'])[fin])
+    assert_grad_close(gz.cpu().numpy()[fin], np.asarray(gold['grad_z'])[fin])
+    loss, g_loc, g_raw = f(()), f(pu), f(pu)
+    nat.check(lib.bvi_advi_meanfield_grads(s, pu, ptr(lp), ptr(gz), ptr(eps), ptr(raw), ptr(loss), ptr(g_loc),
+                                           ptr(g_raw), st), 'grads')
+    assert float(loss) == pytest.approx(gold['loss'], rel=RTOL)
+    assert_grad_close(g_loc.cpu().numpy()[None], np.asarray(gold['grad']['loc'])[None])
+    assert_grad_close(g_raw.cpu().numpy()[None], np.asarray(gold['grad']['raw_scale'])[None])
+    step = torch.zeros((), dtype=torch.float64, device=gpu_device)
+    lr = gold['learning_rate']
+    for i, (x, g, name) in enumerate(((loc, g_loc, 'loc'), (raw, g_raw, 'raw_scale'))):
+        m, v = torch.zeros_like(x), torch.zeros_like(x)
+        before = x.clone()
+        nat.check(lib.bvi_clip_adam_step(pu, ptr(x), ptr(g), ptr(m), ptr(v), ptr(step), 1 if i == 0 else 0, lr, 0.9,
+                                         0.999, 1e-7, 1.0, st), 'clip_adam')
+        assert_grad_close(g.cpu().numpy()[None], np.asarray(gold['clipped'][name])[None])       # clipped in place
+        upd = (x - before).cpu().numpy()
+        np.testing.assert_allclose(upd, np.asarray(gold['after_adam'][name]) - np.asarray(gold[name]), rtol=1e-4,
+                                   atol=1e-5 * lr)
+    assert float(step) == 1.0
+
