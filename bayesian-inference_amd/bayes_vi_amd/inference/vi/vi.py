@@ -191,7 +191,9 @@ class VI(Inference):
         `capture_graph` (default: on for GPU runs with the built-in `Adam`): after three eager steps
         the whole step -- sampling, fused log-posterior pass, backward, clipping, optimizer update -- is
         captured once as a HIP graph and replayed, which removes the per-kernel launch cost that
-        dominates on small datasets.  The steps and their results are the same either way."""
+        dominates on small datasets.  The steps and their results are the same either way.  (A caller that evaluated
+        `loss()` itself beforehand must not keep that loss tensor alive into `fit`: its autograd graph pins the
+        parameters' gradient accumulators to the stream it ran on, and torch then ties the capturing stream to it.)"""
         optimizer = optimizer if optimizer is not None else Adam()
         params = [p for p in self.surrogate_posterior.parameters() if p.requires_grad]
         on_gpu = self.device.type == 'cuda'

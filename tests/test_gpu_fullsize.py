@@ -646,3 +646,128 @@ def test_vi_step_10m_rows_graph_replay_equals_eager(regression_10m, gpu_device):
     assert torch.equal(static_loss, loss_e)
     for p, e in zip(params, eager):
         assert torch.equal(p.detach(), e)
+
+
+# ---- configs[4], second half: the Hamiltonian normalizing flow on the same 10M-row regression ----
+def _hnf_setup(r, gpu_device, sur=None, rows=None):
+    """VI over NormalizingFlow(Chain of two HamiltonianFlow bijectors, 2 leapfrog steps, hidden [128, 128]) with Pu
+    extra dimensions and an MLP lift distribution: linear-regression-example.ipynb cell 13 on the D = 64 model
+    (flow_bijectors.py:15-85, surrogate_posteriors.py:153-212)."""
+    import collections
+    import bayes_vi_amd.distributions as tfd
+    from bayes_vi_amd import symbolic
+    from bayes_vi_amd.inference.vi import VI
+    from bayes_vi_amd.inference.vi.flow_bijectors import Chain, HamiltonianFlow, make_scale_fn, make_shift_fn
+    from bayes_vi_amd.inference.vi.surrogate_posteriors import NormalizingFlow
+    from bayes_vi_amd.model import Model
+    from bayes_vi_amd.utils.datasets import TensorDataset
+    d = r['d']
+    priors = collections.OrderedDict(b=tfd.Normal(0., 10.), w=tfd.Normal(torch.zeros(d), 10.), scale=tfd.HalfNormal(10.))
+    model = Model(priors, lambda b, w, scale, features: tfd.Normal(loc=b + symbolic.matvec(features, w), scale=scale))
+    if sur is None:
+        nd = model.flat_unconstrained_param_event_ndims
+        torch.manual_seed(17)
+        flows = Chain([HamiltonianFlow(event_dims=nd, step_sizes=torch.nn.Parameter(torch.tensor(0.1)),
+                                       num_integration_steps=2, hidden_layers=[128, 128]) for _ in range(2)])
+        shift_fn, scale_fn = make_shift_fn(nd, hidden_layers=[128, 128]), make_scale_fn(nd, hidden_layers=[128, 128])
+        lift = lambda q: tfd.MultivariateNormalDiag(loc=shift_fn(q), scale_diag=scale_fn(q))
+        sur = NormalizingFlow(model, flow_bijector=flows, extra_ndims=nd, posterior_lift_distribution=lift)
+    else:
+        sur.model = model
+    lo, hi = rows if rows is not None else (0, r['n'])
+    return model, VI(model, TensorDataset(r['X'][lo:hi], r['y'][lo:hi]), sur)
+
+
+def test_hnf_elbo_step_10m_rows_256_samples(regression_10m, gpu_device):
+    """configs[4] with the flow surrogate at full size, through VI.loss / VI._step:
+    (i) loss and the gradient of EVERY trainable variable (flow step sizes, energy networks, lift networks) over two
+        row shards add up to those of the whole dataset once the data-free part of the loss (log q - log prior - lift
+        density) is counted once -- what the all-reduce of partial log-likelihoods under the autograd node relies on;
+    (ii) one optimisation step replayed as a HIP graph leaves the variables the eagerly executed step leaves."""
+    from bayes_vi_amd.inference.vi.vi import Adam
+    r = regression_10m
+    n, d, S = r['n'], r['d'], 256
+    pu = d + 2
+    g = torch.Generator(device=gpu_device); g.manual_seed(123)
+    eps = torch.randn(S, 2 * pu, generator=g, device=gpu_device)
+    model, vi = _hnf_setup(r, gpu_device)
+    sur = vi.surrogate_posterior
+    sur.base_noise = lambda m, dim: eps
+    params = [p for p in sur.parameters() if p.requires_grad]
+    assert len(params) >= 2 * (1 + 2 * 6) + 2 * 6          # 2 flows x (step + two 3-layer MLPs) + two 3-layer lift MLPs
+
+    def loss_and_grads(v):
+        for p in params:
+            p.grad = None
+        l = v.loss(S); l.backward()
+        return l.detach().double(), [torch.zeros_like(p, dtype=torch.float64) if p.grad is None else p.grad.double().clone()
+                                     for p in params]
+    full_l, full_g = loss_and_grads(vi)
+    assert bool(torch.isfinite(full_l)) and all(bool(torch.isfinite(t).all()) for t in full_g)
+    assert sum(float(t.abs().max()) > 0 for t in full_g) >= len(params) - 2
+    cut = 6_100_003
+    acc_l, acc_g = torch.zeros((), dtype=torch.float64, device=gpu_device), [torch.zeros_like(t) for t in full_g]
+    for rows in ((0, cut), (cut, n)):
+        _, vs = _hnf_setup(r, gpu_device, sur=sur, rows=rows)
+        l, gs = loss_and_grads(vs)
+        acc_l += l
+        for a, t in zip(acc_g, gs):
+            a += t
+        del vs
+    # the data-free part, counted twice above: the same loss with the likelihood left out of the target
+    p_c = model.flat_param_event_ndims
+    prior_only = sur.get_corrected_target_log_prob_fn(lambda sample: vi.posterior.log_prior(sample[:, :p_c], False)[0])
+    for p in params:
+        p.grad = None
+    q, logq = sur.sample_and_log_prob(S)
+    l0 = (logq - prior_only(q)).mean(); l0.backward()
+    g0 = [torch.zeros_like(t) if p.grad is None else p.grad.double() for p, t in zip(params, full_g)]
+    l0_value = l0.detach().double()
+    # nothing may keep this autograd graph alive into the capture below: its AccumulateGrad nodes belong to the
+    # default stream, and torch then synchronises the capturing stream with it
+    del l0, q, logq
+    assert abs(float(acc_l - l0_value - full_l)) <= 2 * RTOL * abs(float(full_l))
+    worst = 0.0
+    for a, z0, f in zip(acc_g, g0, full_g):
+        scale = float(f.abs().max())
+        if scale == 0.0:
+            assert float((a - z0).abs().max()) == 0.0
+            continue
+        worst = max(worst, float((a - z0 - f).abs().max()) / scale)
+    # every variable's gradient is a linear image of d loss / d sample, which adds over shards to 1e-5 of its largest
+    # entry; the float32 backward passes through the networks round each of the three runs separately
+    assert worst <= 1e-4, worst
+    # (ii) eager step against graph replay from the same state, in the order VI.fit uses: a few eager steps first
+    # (every kernel and autograd path has run once), then capture of the same step with the same optimizer state
+    opt = Adam(learning_rate=1e-3).bind(params)
+    for _ in range(3):
+        vi._step(opt, params, S)
+
+    def snapshot():
+        return ([p.detach().clone() for p in params], [t.clone() for t in opt.m], [t.clone() for t in opt.v],
+                opt.t.clone())
+
+    def restore(snap):
+        with torch.no_grad():
+            for dst, src in zip(params, snap[0]):
+                dst.copy_(src)
+            for dst, src in zip(opt.m + opt.v, snap[1] + snap[2]):
+                dst.copy_(src)
+            opt.t.copy_(snap[3])
+    state0 = snapshot()
+    loss_e = vi._step(opt, params, S).clone()
+    eager = [p.detach().clone() for p in params]
+    assert any(not torch.equal(a, b) for a, b in zip(eager, state0[0]))
+    restore(state0)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = vi._step(opt, params, S)
+    restore(state0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float(opt.t) == float(state0[3]) + 1.0
+    assert float((static_loss - loss_e).abs()) <= 1e-6 * float(loss_e.abs())
+    for p, e in zip(params, eager):
+        # an Adam step moves every entry by ~lr; the two executions may differ in the last bits of the gradients
+        assert float((p.detach() - e).abs().max()) <= 1e-3 * 1e-3 + 1e-6 * float(e.abs().max())
