@@ -179,6 +179,30 @@ def test_linreg_f16_pieces(nat, ws, gpu_device, d, c, n):
     assert_grad_close(g, ref_g, term_scale=_linreg_term_scale(X, y, th))
 
 
+# The three tests below compare the f16-plane kernel with the exact-f32 kernel's own error against the float64 oracle:
+# any float32 evaluation rounds the fitted values to 1e-7 of their size, which near the mode -- where the gradient is
+# a small difference of large sums -- is a floor above the 1e-5 bar ("f32 floor": the reference's float32 TFP graph
+# sits on it as well).  A ratio alone would let both kernels regress together, so every case also has an absolute
+# ceiling: the error measured when the test was written (MI355X, the seeds below) with a factor 2 of headroom.
+F32_FLOOR_CEILINGS = {          # case: (f16-plane kernel, exact-f32 kernel); measured values in the comments
+    'near mode, 128 chains': (1.1e-6, 1.1e-5),            # 5.2e-7, 5.4e-6
+    'near mode, 48 chains': (6e-7, 1.2e-5),               # 2.6e-7, 5.6e-6
+    'at the mode, small weights': (3.2e-6, 2.8e-6),       # 1.6e-6, 1.4e-6
+    'signal / noise, sigma 0.1': (1.4e-5, 4.5e-5),        # 7.0e-6, 2.2e-5
+    'signal / noise, sigma 0.01': (2.7e-4, 3.6e-4),       # 1.3e-4, 1.8e-4
+    'signal / noise, sigma 0.001': (2.2e-3, 3.5e-3),      # 1.1e-3, 1.7e-3
+}
+
+
+def _check_f32_floor(case, e16, e32, ratio, slack=0.0):
+    print('f32 floor [%s]: f16-plane kernel %.3e, exact-f32 kernel %.3e (of the chain\'s largest gradient entry)'
+          % (case, e16, e32))
+    assert e16 <= ratio * e32 + slack, (case, e16, e32)
+    ceiling = F32_FLOOR_CEILINGS.get(case)
+    assert ceiling is not None, 'no recorded ceiling for %s: measured f16 %.3e, f32 %.3e' % (case, e16, e32)
+    assert e16 <= ceiling[0] and e32 <= ceiling[1], (case, e16, e32, ceiling)
+
+
 @pytest.mark.parametrize('c', [128, 48])
 def test_linreg_f16_pieces_near_mode(nat, ws, gpu_device, c):
     """Chains packed tightly around the mode: the gradient is a small difference of large sums and an
@@ -195,7 +219,7 @@ def test_linreg_f16_pieces_near_mode(nat, ws, gpu_device, c):
     e16 = (np.abs(g - ref_g) / scale).max()
     e32 = (np.abs(g32.cpu().numpy() - ref_g) / scale).max()
     assert_logp_close(lp, ref_lp)
-    assert e16 <= max(4.0 * e32, 1e-5), (e16, e32)
+    _check_f32_floor('near mode, %d chains' % c, e16, max(e32, 2.5e-6), 4.0)
 
 
 def test_linreg_f16_pieces_at_the_mode_small_weights(nat, ws, gpu_device):
@@ -222,7 +246,7 @@ def test_linreg_f16_pieces_at_the_mode_small_weights(nat, ws, gpu_device):
     e16 = (np.abs(g - ref_g)[:, 1:1 + d] / scale).max()
     e32 = (np.abs(g32.cpu().numpy() - ref_g)[:, 1:1 + d] / scale).max()
     assert_logp_close(lp, ref_lp)
-    assert e16 <= 3.0 * e32, (e16, e32)
+    _check_f32_floor('at the mode, small weights', e16, e32, 3.0)
 
 
 @pytest.mark.parametrize('sigma', [0.1, 0.01, 0.001])
@@ -250,7 +274,7 @@ def test_linreg_f16_pieces_high_signal_to_noise(nat, ws, gpu_device, sigma):
     scale = np.abs(ref_g[:, 1:1 + d]).max(-1, keepdims=True)
     e16 = (np.abs(g - ref_g)[:, 1:1 + d] / scale).max()
     e32 = (np.abs(g32.cpu().numpy() - ref_g)[:, 1:1 + d] / scale).max()
-    assert e16 <= 2.0 * e32 + 1e-6, (e16, e32)
+    _check_f32_floor('signal / noise, sigma %g' % sigma, e16, e32, 2.0, slack=1e-6)
     # the log-density: inside the 1e-5 bar with room to spare, and at the level of the exact-f32 kernel's own error
     # (at signal / noise ~ 8000 both are set by the f32 rounding of the fitted values: ~1.5e-6 for that kernel)
     rel = (np.abs(lp - ref_lp) / np.abs(ref_lp)).max()
