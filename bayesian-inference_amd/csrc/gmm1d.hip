@@ -150,26 +150,28 @@ __device__ __forceinline__ void mix_row(float yj, float keep, unsigned act, cons
 
 // Four rows per lane with one test per component for all four (the few-chain kernel, whose lanes hold rows: the
 // scalar test-and-branch per component costs as much as a component's arithmetic for one row).
-template <int K, bool GRAD>
-__device__ __forceinline__ void mix_rows4_skip(const float (&y)[4], unsigned act, const MixParams<K>& p,
+template <int K, bool GRAD, int R = 4>
+__device__ __forceinline__ void mix_rows4_skip(const float (&y)[R], unsigned act, const MixParams<K>& p,
                                                float (&acc)[1 + 3 * K]) {
-  float u[GRAD ? K : 1][4], e[GRAD ? K : 1][4];
+  float u[GRAD ? K : 1][R], e[GRAD ? K : 1][R];
   if (GRAD) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < R; ++r) {
         asm volatile("" : "=v"(e[k][r]));
         asm volatile("" : "=v"(u[k][r]));
       }
   }
-  float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssum[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) ssum[r] = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if (act & (1u << k)) {
       asm volatile("" ::);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < R; ++r) {
         const float uu = (y[r] - p.mu[k]) * p.isg[k];
         const float ee = __builtin_amdgcn_exp2f(fmaf(-uu, uu, p.Bp[k]));
         ssum[r] += ee;
@@ -177,10 +179,10 @@ __device__ __forceinline__ void mix_rows4_skip(const float (&y)[4], unsigned act
       }
     }
   }
-  bool near[4];
-  float inv[4];
+  bool near[R];
+  float inv[R];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < R; ++r) {
     near[r] = ssum[r] >= kMixNear;
     acc[0] += near[r] ? __builtin_amdgcn_logf(ssum[r]) : 0.f;
     if (GRAD) inv[r] = near[r] ? __builtin_amdgcn_rcpf(ssum[r]) : 0.f;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void mix_rows4_skip(const float (&y)[4], unsigned act
       if (act2 & (1u << k)) {
         asm volatile("" ::);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < R; ++r) {
           const float rho = e[k][r] * inv[r];
           const float ru = rho * u[k][r];
           acc[1 + k] += rho;
@@ -204,7 +206,7 @@ __device__ __forceinline__ void mix_rows4_skip(const float (&y)[4], unsigned act
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < R; ++r)
     if (__builtin_expect(!near[r], 0)) mix_row_far<K, GRAD>(y[r], 1.f, p, acc);
 }
 
@@ -376,7 +378,7 @@ __device__ __forceinline__ float mix_wave_extreme(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// Few chains per group (CG = 1 or 4): every lane streams rows of its own with 16-byte loads and carries the
+// Few chains per group (CG = 1, 2 or 4): every lane streams rows of its own with 16-byte loads and carries the
 // sums of all CG chains in registers; the chains' parameters are wave-uniform (scalar registers).  The shuffle
 // mapping above issues one 4-byte load per lane and iteration, which leaves too little in flight when the
 // per-row work is small (one or a few chains).  Lanes hold different rows here, so a component can be left out
@@ -428,31 +430,36 @@ __global__ __launch_bounds__(256) void gmm1d_rows_kernel(const float* __restrict
   unsigned long long all_real = 0;
 #pragma unroll
   for (int g = 0; g < CG; ++g) all_real |= (unsigned long long)((1u << kreal) - 1u) << (g * K);
-  // With the gradient and four chains the two forms together need every register there is and the skipping form
-  // then costs more than it saves (measured, rows in ascending order: 1.24 ms against 1.06 at N = 100M, K = 8):
-  // those launches evaluate every component.
-  constexpr bool kRange = !(GRAD && CG > 1);
-  bool probing = kRange;     // wave-uniform: cleared by the first group of rows that spans every component
+  // With the gradient and four chains the branch-free four-row form and the skipping form together need more
+  // registers than there are: those launches keep the skipping form only (rows in no particular order then pay its
+  // eight tests per chain and group of four rows with every bit set, ~10 %).
+  constexpr bool kSkipOnly = GRAD && CG > 1;
+  bool probing = true;       // wave-uniform: cleared by the first group of rows that spans every component
   auto rows4 = [&](const f32x4& v) __attribute__((always_inline)) {
-    if (!probing) {
+    unsigned long long act = all_real;
+    if (probing) {
+      const float lmin = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), lmax = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+      const float ymin = mix_wave_extreme<false>(lmin), ymax = mix_wave_extreme<true>(lmax);
+      act = __builtin_amdgcn_ballot_w64(!(my_hi < ymin || my_lo > ymax)) & kAll;
+      if ((act & all_real) == all_real) probing = false;       // rows in no particular order: stop looking
+    }
+    if (!kSkipOnly && (act & all_real) == all_real) {
       row(v.x); row(v.y); row(v.z); row(v.w);
       return;
     }
-    const float lmin = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), lmax = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-    const float ymin = mix_wave_extreme<false>(lmin), ymax = mix_wave_extreme<true>(lmax);
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(!(my_hi < ymin || my_lo > ymax)) & kAll;
-    if ((act & all_real) == all_real) {
-      probing = false;       // rows in no particular order: stop looking
-      row(v.x); row(v.y); row(v.z); row(v.w);
-    } else {
 #pragma unroll
-      for (int g = 0; g < CG; ++g) {
-        const unsigned ag = (unsigned)(act >> (g * K)) & ((1u << K) - 1u);
+    for (int g = 0; g < CG; ++g) {
+      const unsigned ag = (unsigned)(act >> (g * K)) & ((1u << K) - 1u);
+      if (kSkipOnly) {     // two rows per component test: half the temporaries, three waves per SIMD instead of two
+        const float ya[2] = {v.x, v.y}, yb[2] = {v.z, v.w};
+        mix_rows4_skip<K, GRAD, 2>(ya, ag, p[g], acc[g]);
+        mix_rows4_skip<K, GRAD, 2>(yb, ag, p[g], acc[g]);
+      } else {
         const float yr[4] = {v.x, v.y, v.z, v.w};
         mix_rows4_skip<K, GRAD>(yr, ag, p[g], acc[g]);
       }
-      rows += 4.f;
     }
+    rows += 4.f;
   };
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   int64_t head = (int64_t)(((16 - ((uintptr_t)y & 15)) & 15) >> 2);
@@ -546,41 +553,74 @@ size_t bvi_ws_gmm1d(int64_t n, int c, int k) {
   return (size_t)gmm1d_blocks(n) * c * (1 + 3 * k) * sizeof(float);
 }
 
+// Row blocks of a few-chain launch: as many as are resident at once (the kernel's own occupancy x the CUs, shared out
+// over the chain groups), so that the grid is one full round of workgroups of equal work.  With the fixed 1024 row
+// blocks a kernel that fits 3 workgroups per CU ran a full round and a third of one (N = 100M, K = 8, one chain with
+// gradient: 0.250 -> 0.223 ms; four chains: 0.656 -> 0.619).  Never more than `cap` (what the workspace was sized for).
+template <typename Kern>
+static int gmm1d_resident_blocks(Kern kern, int groups, int cap) {
+  static int per_cu = 0, cus = 0;            // one pair per instantiation of this template, i.e. per kernel
+  if (per_cu == 0) {
+    int dev = 0, nblk = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+      cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, kern, 256, 0) != hipSuccess || nblk < 1) nblk = 1;
+    per_cu = nblk;
+  }
+  const int nb = per_cu * cus / (groups < 1 ? 1 : groups);
+  return nb < 1 ? 1 : (nb > cap ? cap : nb);
+}
+
+// Launches the streaming kernel for `c` chains in groups of `cp`; returns the number of row blocks it used.
 template <int K, bool GRAD>
-static void gmm1d_dispatch_cp(int cp, dim3 grid, hipStream_t s, const float* y, int64_t n, int k,
-                              const float* theta, int c, float* ws) {
+static int gmm1d_dispatch_cp(int cp, int nb, hipStream_t s, const float* y, int64_t n, int k, const float* theta, int c,
+                             float* ws) {
+  dim3 grid(nb, bvi_ceil_div(c, cp));
   // bins of the component table: building it costs a block ~8 instructions per bin and component, so it is sized
   // to the rows a block streams (none at all for short inputs: every component is then evaluated)
   const int64_t rows_per_block = n / grid.x;
   const int nbins = rows_per_block >= 16384 ? kMixMaxBins : rows_per_block >= 2048 ? 128 : 0;
-  switch (cp) {
-    case 1: hipLaunchKernelGGL((gmm1d_rows_kernel<K, 1, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, ws); break;
-    case 4:
-      if (K <= 8) hipLaunchKernelGGL((gmm1d_rows_kernel<K <= 8 ? K : 8, 4, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, ws);
-      else hipLaunchKernelGGL((gmm1d_kernel<K, 4, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws);
-      break;
-    case 16: hipLaunchKernelGGL((gmm1d_kernel<K, 16, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws); break;
-    default: hipLaunchKernelGGL((gmm1d_kernel<K, 64, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws); break;
+  constexpr int KR = K <= 8 ? K : 8;         // the few-chain kernels exist for K <= 8
+  if (cp == 1) {
+    auto kern = gmm1d_rows_kernel<K, 1, GRAD>;
+    if (n >= (int64_t)nb * 1024) grid.x = gmm1d_resident_blocks(kern, grid.y, nb);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+  } else if (cp == 4 && K <= 8 && GRAD) {
+    // with the gradient, two chains per lane group (four need more registers than a wave has: one wave per SIMD)
+    auto kern = gmm1d_rows_kernel<KR, 2, GRAD>;
+    grid.y = bvi_ceil_div(c, 2);
+    if (n >= (int64_t)nb * 1024) grid.x = gmm1d_resident_blocks(kern, grid.y, nb);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+  } else if (cp == 4 && K <= 8) {
+    auto kern = gmm1d_rows_kernel<KR, 4, GRAD>;
+    if (n >= (int64_t)nb * 1024) grid.x = gmm1d_resident_blocks(kern, grid.y, nb);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, y, n, k, theta, c, ws);
+  } else if (cp == 4) {
+    hipLaunchKernelGGL((gmm1d_kernel<K, 4, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws);
+  } else if (cp == 16) {
+    hipLaunchKernelGGL((gmm1d_kernel<K, 16, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws);
+  } else {
+    hipLaunchKernelGGL((gmm1d_kernel<K, 64, GRAD>), grid, dim3(256), 0, s, y, n, k, theta, c, nbins, ws);
   }
+  return (int)grid.x;
 }
 
 template <bool GRAD>
-static void gmm1d_dispatch_k(int cp, dim3 grid, hipStream_t s, const float* y, int64_t n, int k, const float* theta,
-                             int c, float* ws) {
-  if (k <= 2) gmm1d_dispatch_cp<2, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
-  else if (k <= 4) gmm1d_dispatch_cp<4, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
-  else if (k <= 8) gmm1d_dispatch_cp<8, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
-  else gmm1d_dispatch_cp<16, GRAD>(cp, grid, s, y, n, k, theta, c, ws);
+static int gmm1d_dispatch_k(int cp, int nb, hipStream_t s, const float* y, int64_t n, int k, const float* theta, int c,
+                            float* ws) {
+  if (k <= 2) return gmm1d_dispatch_cp<2, GRAD>(cp, nb, s, y, n, k, theta, c, ws);
+  if (k <= 4) return gmm1d_dispatch_cp<4, GRAD>(cp, nb, s, y, n, k, theta, c, ws);
+  if (k <= 8) return gmm1d_dispatch_cp<8, GRAD>(cp, nb, s, y, n, k, theta, c, ws);
+  return gmm1d_dispatch_cp<16, GRAD>(cp, nb, s, y, n, k, theta, c, ws);
 }
 
 int bvi_launch_gmm1d(const float* y, int64_t n, int k, const float* theta, int c, float* logp, float* grad,
                      float* ws, hipStream_t s, const double* logp_ref) {
   if (k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
-  const int nb = gmm1d_blocks(n);
   const int cp = bvi_chain_pack(c);
-  dim3 grid(nb, bvi_ceil_div(c, cp));
-  if (grad) gmm1d_dispatch_k<true>(cp, grid, s, y, n, k, theta, c, ws);
-  else gmm1d_dispatch_k<false>(cp, grid, s, y, n, k, theta, c, ws);
+  const int nb = grad ? gmm1d_dispatch_k<true>(cp, gmm1d_blocks(n), s, y, n, k, theta, c, ws)
+                      : gmm1d_dispatch_k<false>(cp, gmm1d_blocks(n), s, y, n, k, theta, c, ws);
   BVI_HIP_CHECK_LAUNCH();
   const int tot = c * 3 * k;
   if (nb > 32)

@@ -337,14 +337,15 @@ def test_mixture_component_table(nat, ws, gpu_device, n, case):
     assert torch.equal(lpb[[0, 2, c - 1]], lp[[0, 2, c - 1]])
 
 
-@pytest.mark.parametrize('c', [1, 3])
+@pytest.mark.parametrize('c', [1, 2, 3, 4])
 @pytest.mark.parametrize('case', ['separated', 'overlapping', 'k16'])
 def test_mixture_few_chains_rows_in_ascending_order(nat, ws, gpu_device, c, case):
     """The few-chain kernel (lanes hold rows) leaves a component out for the 256 rows a wave has loaded when all of
     them are out of its reach, which happens when the rows are stored in ascending order (what the host layer does).
     Same inputs in ascending and in the original order, against float64: separated components (most are left out),
     overlapping ones (none is), K = 16 (one chain per group), a stretch of rows no component reaches, a NaN row's
-    worth of propagation, one chain with a NaN mean; the value-only launch returns the same log densities."""
+    worth of propagation, one chain with a NaN mean; the value-only launch returns the same log densities.  Two to
+    four chains with the gradient run as groups of two chains (the last group of three chains holds one)."""
     n = 5_000_011
     g = torch.Generator(device=gpu_device); g.manual_seed(23)
     k = {'separated': 8, 'overlapping': 6, 'k16': 16}[case]
