@@ -428,6 +428,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   __shared__ float sq[FW * KQ][FT + 4];   // sqrt(rho_ik) of the tile (0 for rows past the end)
   __shared__ float cks[FW * KQ];        // the components' constants
   __shared__ float lpw[FT];
+  // actf[q][kp][w] != 0: component kp + FW q has a responsibility worth multiplying among rows 8 w .. 8 w + 7 of the tile
+  __shared__ __attribute__((aligned(8))) unsigned char actf[2][FW][FW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool lead_wave = __builtin_amdgcn_readfirstlane(wave) < FW / 2;      // wave-uniform, in a scalar register
@@ -666,16 +668,28 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
         // a row whose |u|^2 = 2 (const - a) is beyond the f16 range of w (absurd parameters) is dropped from
         // the gradient sums instead of turning them into NaN; its log-density is already counted
         const float lsev = valid ? lse : INFINITY;
+        float s0 = 0.f, s1 = 0.f;
         if (v0) {
-          const float s = (a0 > cks[kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a0 - lsev));
-          sq[kp][row] = s;
-          S0a = fmaf(s, s, S0a);
+          s0 = (a0 > cks[kp] - 1.5e9f ? 1.f : 0.f) * __builtin_amdgcn_exp2f(0.72134752f * (a0 - lsev));
+          sq[kp][row] = s0;
+          S0a = fmaf(s0, s0, S0a);
         }
         if (v1) {
-          const float s = (a1 > cks[KQ == 2 ? kp + FW : kp] - 1.5e9f ? 1.f : 0.f) *
-                          __builtin_amdgcn_exp2f(0.72134752f * (a1 - lsev));
-          sq[KQ == 2 ? kp + FW : kp][row] = s;
-          S0b = fmaf(s, s, S0b);
+          s1 = (a1 > cks[KQ == 2 ? kp + FW : kp] - 1.5e9f ? 1.f : 0.f) *
+               __builtin_amdgcn_exp2f(0.72134752f * (a1 - lsev));
+          sq[KQ == 2 ? kp + FW : kp][row] = s1;
+          S0b = fmaf(s1, s1, S0b);
+        }
+        // Which components have, among this wave's eight rows, a responsibility the raw-sums phase can see: w =
+        // sqrt(rho) u goes into f16 pieces, so sqrt(rho) < 2^-20 (rho < 2^-40) leaves nothing of a row in S2 and
+        // less than 2^-40 |u| of it in S1.  A 32-row half of the tile without such a row for a component skips
+        // that component's share of the phase -- most of it when neighbouring rows belong to the same few
+        // components (rows stored cluster by cluster; any order is correct).  NaN counts as worth multiplying.
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(!(s0 < 9.5367431640625e-07f));
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(!(s1 < 9.5367431640625e-07f));
+        if (lane < FW) {
+          actf[0][lane][wave] = ((m0 >> lane) & 0x0101010101010101ull) != 0 ? 1 : 0;
+          actf[1][lane][wave] = ((m1 >> lane) & 0x0101010101010101ull) != 0 ? 1 : 0;
         }
       }
     }
@@ -687,8 +701,11 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       if (lead_wave == (q != 0)) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
       if (k < K) {
+        // rows 0 .. 31 were looked at by waves 0 .. 3 (bytes 0 .. 3), rows 32 .. 63 by waves 4 .. 7
+        const uint2 seen = *reinterpret_cast<const uint2*>(&actf[q][wave][0]);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {        // 32-row pairs: k index j <-> row 32 m + 16 (j >> 2) + 4 g + (j & 3)
+          if (__builtin_amdgcn_readfirstlane(m == 0 ? seen.x : seen.y) == 0) continue;
           float sr[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
