@@ -248,10 +248,13 @@ def cluster_row_order(Y, k, seed=0):
             assign[s0:s0 + step] = (cn[None, :] - 2.0 * (y @ c32.T)).argmin(-1)
         if it == 2:
             break
-        cnt = torch.bincount(assign, minlength=m).double()
+        # centre sums as one-hot^T @ rows per chunk (a scatter-add into 4 k targets would serialise on its atomics)
+        cnt = torch.zeros(m, dtype=torch.float64, device=Y.device)
         tot = torch.zeros(m, d, dtype=torch.float64, device=Y.device)
         for s0 in range(0, n, step):
-            tot.index_add_(0, assign[s0:s0 + step], Y[s0:s0 + step].double())
+            hot = torch.nn.functional.one_hot(assign[s0:s0 + step], m).to(torch.float32)
+            tot += (hot.T @ Y[s0:s0 + step]).double()
+            cnt += hot.sum(0).double()
         cent = torch.where(cnt[:, None] > 0, tot / cnt.clamp_min(1.0)[:, None], cent)
     return torch.sort(assign, stable=True).indices
 

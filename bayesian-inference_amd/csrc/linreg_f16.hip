@@ -11,7 +11,7 @@
 //   S2 = S2_k - 2 (w . cr + dw . G_k)                        cr = t1 - B (w - dw),  B = XR^T XH
 //        + w . A w - 2 w . B (w - dw) + dw . (X^T X - A) dw
 // with X^T X, A, B (D x D) and XR^T y, XR^T 1 (D) in double behind the header of the packed dataset
-// (f16_gram_kernel, f16_low_kernel; A is accumulated term by term as xh_f xr_g + xr_f x_g, so nothing cancels).
+// (f16_sums_kernel; A is accumulated term by term as xh_f xr_g + xr_f x_g, so nothing cancels).
 // xr and dw are 2^-12-sized, so are the corrections: they are error compensation, far from the cancellation a
 // Gram-matrix evaluation of the whole likelihood would suffer -- r_k differs from r by ~2^-12 of the fitted
 // values, and the f32 sums of the kernel stay accurate as long as that is not far above the residuals themselves
@@ -915,67 +915,125 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 // Run twice: first on the columns as they are (shift == nullptr: the sums give the column means), then on the
 // centred columns x - shift (abs-max for the column scales; the sum of the exact differences).
 template <int D>
-__global__ void f16_colstats_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n, int dr,
-                                    const float* __restrict__ shift, float* __restrict__ pmax,
-                                    double* __restrict__ psum) {
-  // 256 threads = 256 / D row lanes x D columns
-  constexpr int RL = 256 / D;
-  const int col = threadIdx.x % D, rl = threadIdx.x / D;
-  const double m = (shift && col < dr) ? (double)shift[col] : 0.0;
-  float amax = 0.f;
+__global__ __launch_bounds__(256) void f16_colstats_kernel(const float* __restrict__ X, const float* __restrict__ y,
+                                                           int64_t n, int dr, const float* __restrict__ shift,
+                                                           float* __restrict__ pmax, double* __restrict__ psum) {
+  // 256 threads = RL row lanes x D / 4 column groups: a thread owns four neighbouring columns (one 16-byte load per
+  // row when the rows are D floats long and 16-byte aligned; element loads otherwise), four rows in flight
+  constexpr int CGR = D / 4, RL = 256 / CGR;
+  const int cg = threadIdx.x % CGR, rl = threadIdx.x / CGR, c0 = 4 * cg;
+  double m[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = (shift && c0 + j < dr) ? (double)shift[c0 + j] : 0.0;
+  float amax[4] = {0.f, 0.f, 0.f, 0.f};
   float yhi = -INFINITY, ylo = INFINITY;      // largest and smallest y (NaN: kept out by fmaxf / fminf, found by ysum)
-  double sum = 0.0, ysum = 0.0;
-  for (int64_t row = (int64_t)blockIdx.x * RL + rl; row < n; row += (int64_t)gridDim.x * RL) {
-    const double v = col < dr ? (double)X[row * dr + col] - m : 0.0;
-    amax = fmaxf(amax, fabsf((float)v));
-    sum += v;
-    if (col == 0) {
-      ysum += (double)y[row];
-      yhi = fmaxf(yhi, y[row]);
-      ylo = fminf(ylo, y[row]);
+  double sum[4] = {0.0, 0.0, 0.0, 0.0}, ysum = 0.0;
+  const bool vec = dr == D && (((uintptr_t)X & 15) == 0);
+  const int64_t stride = (int64_t)gridDim.x * RL;
+  auto take = [&](const float (&v)[4], int64_t row) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double d = c0 + j < dr ? (double)v[j] - m[j] : 0.0;
+      amax[j] = fmaxf(amax[j], fabsf((float)d));
+      sum[j] += d;
+    }
+    if (cg == 0) {
+      const float yv = y[row];
+      ysum += (double)yv;
+      yhi = fmaxf(yhi, yv);
+      ylo = fminf(ylo, yv);
+    }
+  };
+  int64_t row = (int64_t)blockIdx.x * RL + rl;
+  if (vec) {
+    for (; row + 3 * stride < n; row += 4 * stride) {
+      f32x4v q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4v*>(X + (row + u * stride) * D + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v[4] = {q[u][0], q[u][1], q[u][2], q[u][3]};
+        take(v, row + u * stride);
+      }
     }
   }
-  __shared__ float smax[256], syhi[256], sylo[256];
-  __shared__ double ssum[256], sy[256];
-  smax[threadIdx.x] = amax;
-  ssum[threadIdx.x] = sum;
+  for (; row < n; row += stride) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = c0 + j < dr ? X[row * dr + c0 + j] : 0.f;
+    take(v, row);
+  }
+  __shared__ float smax[256][4], syhi[256], sylo[256];
+  __shared__ double ssum[256][4], sy[256];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { smax[threadIdx.x][j] = amax[j]; ssum[threadIdx.x][j] = sum[j]; }
   sy[threadIdx.x] = ysum;
   syhi[threadIdx.x] = yhi;
   sylo[threadIdx.x] = ylo;
   __syncthreads();
   if (rl == 0) {
     for (int q = 1; q < RL; ++q) {
-      amax = fmaxf(amax, smax[q * D + col]);
-      sum += ssum[q * D + col];
-      if (col == 0) {
-        ysum += sy[q * D];
-        yhi = fmaxf(yhi, syhi[q * D]);
-        ylo = fminf(ylo, sylo[q * D]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        amax[j] = fmaxf(amax[j], smax[q * CGR + cg][j]);
+        sum[j] += ssum[q * CGR + cg][j];
+      }
+      if (cg == 0) {
+        ysum += sy[q * CGR];
+        yhi = fmaxf(yhi, syhi[q * CGR]);
+        ylo = fminf(ylo, sylo[q * CGR]);
       }
     }
-    pmax[(int64_t)blockIdx.x * (D + 2) + col] = amax;
-    if (col == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pmax[(int64_t)blockIdx.x * (D + 2) + c0 + j] = amax[j];
+      psum[(int64_t)blockIdx.x * (D + 1) + c0 + j] = sum[j];
+    }
+    if (cg == 0) {
       pmax[(int64_t)blockIdx.x * (D + 2) + D] = yhi;
       pmax[(int64_t)blockIdx.x * (D + 2) + D + 1] = ylo;
+      psum[(int64_t)blockIdx.x * (D + 1) + D] = ysum;
     }
-    psum[(int64_t)blockIdx.x * (D + 1) + col] = sum;
-    if (col == 0) psum[(int64_t)blockIdx.x * (D + 1) + D] = ysum;
   }
 }
 
 // CENTRED = false (after the first statistics pass): the shift vector (column means in f32, 0 where not finite) and
 // the statistics of y; CENTRED = true (after the second): the scales and sums of the centred columns
 template <int D, bool CENTRED>
-__global__ void f16_header_kernel(const float* __restrict__ pmax, const double* __restrict__ psum, int nblk,
-                                    int64_t n, Header* __restrict__ hdr) {
-  const int col = threadIdx.x;
-  if (col < D) {
-    float amax = 0.f;
-    double sum = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+__global__ __launch_bounds__(1024) void f16_header_kernel(const float* __restrict__ pmax, const double* __restrict__ psum,
+                                                          int nblk, int64_t n, Header* __restrict__ hdr) {
+  // 1024 threads = 16 slices x 64 columns: slice s folds the partials s, s + 16, ... of its column, then column
+  // threads of slice 0 fold the 16 slices -- the same order every run (a single thread per column walking all
+  // 1024 partials took half a millisecond)
+  __shared__ float fmx[16][64], fhi[16], flo[16];
+  __shared__ double fsm[16][64], fys[16];
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float amax = 0.f;
+  double sum = 0.0;
+  if (col < D)
+    for (int b = sl; b < nblk; b += 16) {
       amax = fmaxf(amax, pmax[(int64_t)b * (D + 2) + col]);
       sum += psum[(int64_t)b * (D + 1) + col];
     }
+  fmx[sl][col] = amax;
+  fsm[sl][col] = sum;
+  if (col == 0 && !CENTRED) {
+    double ys = 0.0;
+    float yhi = -INFINITY, ylo = INFINITY;
+    for (int b = sl; b < nblk; b += 16) {
+      ys += psum[(int64_t)b * (D + 1) + D];
+      yhi = fmaxf(yhi, pmax[(int64_t)b * (D + 2) + D]);
+      ylo = fminf(ylo, pmax[(int64_t)b * (D + 2) + D + 1]);
+    }
+    fys[sl] = ys; fhi[sl] = yhi; flo[sl] = ylo;
+  }
+  __syncthreads();
+  if (sl != 0) return;
+  for (int q = 1; q < 16; ++q) {
+    amax = fmaxf(amax, fmx[q][col]);
+    sum += fsm[q][col];
+  }
+  if (col < D) {
     if (CENTRED) {
       hdr->colscale[col] = amax > 0.f ? col_scale(amax) : 0.f;   // 0 marks an all-zero (here: constant) column
       hdr->colsum[col] = sum;
@@ -983,7 +1041,7 @@ __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* 
       const float mean = n > 0 ? (float)(sum / (double)n) : 0.f;
       hdr->shift[col] = isfinite(mean) ? mean : 0.f;
     }
-  } else if (col < 64) {
+  } else {
     if (CENTRED) {
       hdr->colscale[col] = 0.f;
       hdr->colsum[col] = 0.0;
@@ -994,10 +1052,10 @@ __global__ void f16_header_kernel(const float* __restrict__ pmax, const double* 
   if (col == 0 && !CENTRED) {
     double ys = 0.0;
     float yhi = -INFINITY, ylo = INFINITY;
-    for (int b = 0; b < nblk; ++b) {
-      ys += psum[(int64_t)b * (D + 1) + D];
-      yhi = fmaxf(yhi, pmax[(int64_t)b * (D + 2) + D]);
-      ylo = fminf(ylo, pmax[(int64_t)b * (D + 2) + D + 1]);
+    for (int q = 0; q < 16; ++q) {
+      ys += fys[q];
+      yhi = fmaxf(yhi, fhi[q]);
+      ylo = fminf(ylo, flo[q]);
     }
     const float ybar = n > 0 ? (float)(ys / (double)n) : 0.f;
     hdr->ysum = ys;
@@ -1041,154 +1099,193 @@ __global__ void f16_pack_kernel(const float* __restrict__ X, const float* __rest
   }
 }
 
-// X^T X (of the centred columns) in double, stage 1: block b takes the 64-row tiles b, b + nblk, ...; a thread owns an E x E block of
-// the matrix (E = D / 16).  Partials [nblk][64][64]; only the D x D corner is written.
-constexpr int kGramBlocks = 256;
-template <int D>
-__global__ __launch_bounds__(256) void f16_gram_kernel(const float* __restrict__ X, int64_t n, int dr,
-                                                       const Header* __restrict__ hdr, double* __restrict__ gpart) {
-  constexpr int E = D / 16;
-  __shared__ double xt[64][D + 1];       // the centred rows x - shift, exact
-  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
-  double acc[E][E];
+// ---- pack-time sums (once per dataset) -------------------------------------------------------------------------
+// With h the f16 plane (as numbers), x' = (x - shift) s the exact scaled entry and r = x' - h what the plane leaves
+// out, the finalize kernel needs, in double,
+//   X^T X = H^T H + A,   A = X^T X - H^T H = P + P^T + R^T R,   Bt = P,   P[f][g] = sum_i h_if r_ig,
+//   XR^T y = sum_i r_i y_i,   XR^T 1 = sum_i r_i
+// (all brought back to the columns' own units at the end: the scales are powers of two).  The three 64 x 64 products
+// run on v_mfma_f32_16x16x4_f32 -- h is an f16 number and r is rounded to f32 once (6e-8 of itself), so every
+// product of two operands is exact to f32 rounding -- as sums over ONE 64-row tile in f32, which each wave then adds
+// to its running totals in double: a tile sum carries ~1e-7 of its own size, independent from tile to tile, and
+// the totals over 10^5 tiles end up good to ~1e-9 of the sums of magnitudes -- far inside what the compensation
+// needs (its terms are 2^-12-sized corrections of sums that are themselves held to 1e-5).  The two vectors are
+// summed in double by the staging threads from the exact r.  Everything is added in a fixed order: the packed
+// dataset is bit-for-bit the same from run to run.  (The first version of these sums ran as 4 x 4 register tiles of
+// double-precision fma on the vector ALU, bound by its LDS reads: 24 ms of a 30 ms pack step at N = 10M, D = 64.)
+//
+// Workgroup = 4 waves with one role each over the staged tile: H^T H (upper tiles), R^T R (upper tiles), and the two
+// halves of P.  A[m = feature][k = row] and B[k = row][n = feature] of a 4-row step are the same LDS reads (lane l:
+// feature 16 t + (l & 15), row 4 step + (l >> 4)); D[m][n]: lane l, register i holds m = 4 (l >> 4) + i, n = l & 15.
+constexpr int kGramBlocks = 512;          // two to three resident per CU: one stages while another multiplies
+constexpr int kSumStride = 3 * 64 * 64 + 128;     // per block: H^T H | R^T R | P | XR^T y | XR^T 1 (doubles)
+static_assert(kSumStride == 64 * 64 + kLowStride, "scratch layout");
+
+// tile t of a role -> feature tiles (ft, gt): roles 0, 1 walk the upper triangle row by row, roles 2, 3 take the
+// upper and lower half of P's tile rows
+constexpr int sums_ft(int role, int ntl, int t) {
+  if (role >= 2) return (role - 2) * (ntl / 2) + t / ntl;
+  int ft = 0, first = 0;
+  while (t >= first + (ntl - ft)) { first += ntl - ft; ++ft; }
+  return ft;
+}
+constexpr int sums_gt(int role, int ntl, int t) {
+  if (role >= 2) return t % ntl;
+  int ft = 0, first = 0;
+  while (t >= first + (ntl - ft)) { first += ntl - ft; ++ft; }
+  return ft + (t - first);
+}
+constexpr int sums_tiles(int role, int ntl) { return role < 2 ? ntl * (ntl + 1) / 2 : ntl * ntl / 2; }
+
+// one staged 64-row tile for one role: 16 steps of 4 rows, tile sums in f32, added to the running totals in double
+template <int D, int ROLE, int NT, int SL>
+__device__ __forceinline__ void sums_tile(const float (*ht)[SL], const float (*rt)[SL], int ln, int g,
+                                          double (&accd)[NT][4]) {
+  constexpr int NTL = D / 16, NTW = sums_tiles(ROLE, NTL);
+  const float (*ma)[SL] = ROLE == 1 ? rt : ht;          // A side: h for H^T H and P, r for R^T R
+  const float (*mb)[SL] = ROLE == 0 ? ht : rt;          // B side: h for H^T H, r for R^T R and P
+  f32x4v accf[NTW];
 #pragma unroll
-  for (int i = 0; i < E; ++i)
+  for (int t = 0; t < NTW; ++t) accf[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int step = 0; step < 16; ++step) {
+    const int row = 4 * step + g;
+    float fa[NTL], fb[NTL];
 #pragma unroll
-    for (int j = 0; j < E; ++j) acc[i][j] = 0.0;
-  const int64_t ntiles = (n + 63) / 64;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * D; e += 256) {
-      const int r = e / D, col = e - r * D;
-      const int64_t row = t * 64 + r;
-      xt[r][col] = (row < n && col < dr) ? (double)X[row * dr + col] - (double)hdr->shift[col] : 0.0;
+    for (int t = 0; t < NTL; ++t) {
+      fa[t] = ma[row][16 * t + ln];
+      fb[t] = ROLE < 2 ? fa[t] : mb[row][16 * t + ln];
     }
-    __syncthreads();
-    for (int r = 0; r < 64; ++r) {
-      double xa[E], xb[E];
-#pragma unroll
-      for (int i = 0; i < E; ++i) {
-        xa[i] = xt[r][E * a + i];
-        xb[i] = xt[r][E * b + i];
-      }
-#pragma unroll
-      for (int i = 0; i < E; ++i)
-#pragma unroll
-        for (int j = 0; j < E; ++j) acc[i][j] = fma(xa[i], xb[j], acc[i][j]);
-    }
+    static_for<NTW>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      accf[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sums_ft(ROLE, NTL, t)], fb[sums_gt(ROLE, NTL, t)], accf[t], 0, 0, 0);
+    });
   }
 #pragma unroll
-  for (int i = 0; i < E; ++i)
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
-    for (int j = 0; j < E; ++j) gpart[((int64_t)blockIdx.x * 64 + E * a + i) * 64 + E * b + j] = acc[i][j];
+    for (int i = 0; i < 4; ++i) accd[t][i] += (double)accf[t][i];
 }
 
-// stage 2: fixed-order sum of the partials; entries outside the D x D corner are zero
-__global__ void f16_gram_final(const double* __restrict__ gpart, int nblk, int D, double* __restrict__ gram) {
+template <int D, int ROLE, int NT>
+__device__ __forceinline__ void sums_store(double* __restrict__ out, int ln, int g, const double (&accd)[NT][4]) {
+  constexpr int NTL = D / 16, NTW = sums_tiles(ROLE, NTL);
+  constexpr int base = ROLE == 0 ? 0 : ROLE == 1 ? 4096 : 8192;
+  static_for<NTW>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int ft = sums_ft(ROLE, NTL, t), gt = sums_gt(ROLE, NTL, t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[base + (16 * ft + 4 * g + i) * 64 + 16 * gt + ln] = accd[t][i];
+  });
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void f16_sums_kernel(const float* __restrict__ X, const float* __restrict__ y,
+                                                       int64_t n, int dr, const Header* __restrict__ hdr,
+                                                       double* __restrict__ part) {
+  constexpr int NTL = D / 16;                    // feature tiles per side
+  constexpr int SL = D + 16;                     // LDS row stride: the four rows of a step land on distinct banks
+  constexpr int NT = sums_tiles(0, NTL) > sums_tiles(2, NTL) ? sums_tiles(0, NTL) : sums_tiles(2, NTL);
+  constexpr int RL = 256 / D;                    // row lanes of the staging
+  __shared__ float ht[64][SL], rt[64][SL];
+  __shared__ double colred[2][256];
+  const int tid = threadIdx.x, lane = tid & 63, ln = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = tid % D, rl = tid / D;
+  const bool cin = col < dr;
+  const float shf = cin ? hdr->shift[col] : 0.f, csf = cin ? hdr->colscale[col] : 0.f;
+  double vy = 0.0, v1 = 0.0;
+  double accd[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accd[t][i] = 0.0;
+
+  const int64_t ntile = (n + 63) / 64;
+  for (int64_t t0 = blockIdx.x; t0 < ntile; t0 += gridDim.x) {
+    __syncthreads();                             // the previous tile's fragments have been read
+#pragma unroll 4
+    for (int r = rl; r < 64; r += RL) {
+      const int64_t row = t0 * 64 + r;
+      const bool in = cin && row < n;
+      const float v = in ? X[row * dr + col] : 0.f;
+      // the pack kernel's rounding for h; x' exact in double (the float rounding of x - shift is part of what the
+      // plane leaves out)
+      const double xd = in ? ((double)v - (double)shf) * (double)csf : 0.0;
+      const float hv = in ? (float)(_Float16)plane_value(v, shf, csf) : 0.f;
+      const double rd = xd - (double)hv;
+      ht[r][col] = hv;
+      rt[r][col] = (float)rd;
+      if (in) {
+        vy = fma(rd, (double)y[row], vy);
+        v1 += rd;
+      }
+    }
+    __syncthreads();
+    // one role per wave; the branches are wave-uniform and every wave comes back to the loop's two barriers
+    if (wave == 0) sums_tile<D, 0, NT, SL>(ht, rt, ln, g, accd);
+    else if (wave == 1) sums_tile<D, 1, NT, SL>(ht, rt, ln, g, accd);
+    else if (wave == 2) sums_tile<D, 2, NT, SL>(ht, rt, ln, g, accd);
+    else sums_tile<D, 3, NT, SL>(ht, rt, ln, g, accd);
+  }
+
+  double* out = part + (int64_t)blockIdx.x * kSumStride;
+  if (wave == 0) sums_store<D, 0, NT>(out, ln, g, accd);
+  else if (wave == 1) sums_store<D, 1, NT>(out, ln, g, accd);
+  else if (wave == 2) sums_store<D, 2, NT>(out, ln, g, accd);
+  else sums_store<D, 3, NT>(out, ln, g, accd);
+  // the two vectors: the RL threads of a column add up in a fixed order
+  colred[0][tid] = vy;
+  colred[1][tid] = v1;
+  __syncthreads();
+  if (rl == 0) {
+    double sy = vy, s1 = v1;
+    for (int q = 1; q < RL; ++q) {
+      sy += colred[0][q * D + col];
+      s1 += colred[1][q * D + col];
+    }
+    out[3 * 4096 + col] = sy;
+    out[3 * 4096 + 64 + col] = s1;
+  }
+}
+
+__device__ __forceinline__ double iq0(const Header* hdr, int q) {
+  const float c = hdr->colscale[q];
+  return c > 0.f ? 1.0 / (double)c : 0.0;
+}
+
+// stage 2: fixed-order sums over the blocks, assembled into X^T X (gram) and A | Bt | XR^T y | XR^T 1 (low) in the
+// columns' own units; entries beyond the model's features are zero.  One thread per matrix entry (p, q).
+__global__ void f16_sums_final(const double* __restrict__ part, int nblk, int D, const Header* __restrict__ hdr,
+                               double* __restrict__ gram, double* __restrict__ low) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= 64 * 64) return;
-  double s = 0.0;
-  if ((e >> 6) < D && (e & 63) < D)
-    for (int b = 0; b < nblk; ++b) s += gpart[(int64_t)b * 4096 + e];
-  gram[e] = s;
-}
-
-// What the f16 plane leaves of the centred X, xr = (x - shift) - xh (in double), enters every sum linearly, so its effect is known
-// in closed form from four pack-time sums in double (see the top of this file):
-//   A  = X^T X - XH^T XH, accumulated term by term as xh_f xr_g + xr_f x_g (no cancellation), symmetric
-//   Bt[g][f] = sum_i xr_if xh_ig,   XR^T y,   XR^T 1.
-// Stage 1, as f16_gram_kernel: block b takes the 64-row tiles b, b + nblk, ...; partials [nblk][kLowStride] =
-// A, Bt, XR^T y, XR^T 1.  Sums are taken in the columns' scales and brought back at the end (exact: powers of two).
-template <int D>
-__global__ __launch_bounds__(256) void f16_low_kernel(const float* __restrict__ X, const float* __restrict__ y,
-                                                      int64_t n, int dr, const Header* __restrict__ hdr,
-                                                      double* __restrict__ lpart) {
-  constexpr int E = D / 16;
-  __shared__ double xt[64][D + 1];       // centred and scaled entries, exact
-  __shared__ float ht[64][D + 1], yt[64];
-  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
-  double accA[E][E], accB[E][E], vy[E], v1[E];
-#pragma unroll
-  for (int i = 0; i < E; ++i) {
-    vy[i] = 0.0;
-    v1[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-      accA[i][j] = 0.0;
-      accB[i][j] = 0.0;
+  const int p = e >> 6, q = e & 63;
+  const bool in = p < D && q < D;
+  double hh = 0.0, rr = 0.0, pq = 0.0, qp = 0.0;
+  if (in) {
+    // the symmetric products hold their upper tiles only
+    const int su = (p >> 4) <= (q >> 4) ? p * 64 + q : q * 64 + p;
+    for (int b = 0; b < nblk; ++b) {
+      const double* o = part + (int64_t)b * kSumStride;
+      hh += o[su];
+      rr += o[4096 + su];
+      pq += o[8192 + p * 64 + q];
+      qp += o[8192 + q * 64 + p];
     }
   }
-  const int64_t ntiles = (n + 63) / 64;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * D; e += 256) {
-      const int r = e / D, col = e - r * D;
-      const int64_t row = t * 64 + r;
-      const bool in = row < n && col < dr;
-      const float v = in ? X[row * dr + col] : 0.f;
-      // the pack kernel's rounding, in the column's scale; xt keeps the exact centred value (the float rounding of
-      // x - shift is part of what the plane leaves out)
-      xt[r][col] = in ? ((double)v - (double)hdr->shift[col]) * (double)hdr->colscale[col] : 0.0;
-      ht[r][col] = in ? (float)(_Float16)plane_value(v, hdr->shift[col], hdr->colscale[col]) : 0.f;
-    }
-    if (threadIdx.x < 64) yt[threadIdx.x] = t * 64 + threadIdx.x < n ? y[t * 64 + threadIdx.x] : 0.f;
-    __syncthreads();
-    for (int r = 0; r < 64; ++r) {
-      double xa[E], ha[E], ra[E], xb[E], hb[E], rb[E];
-#pragma unroll
-      for (int i = 0; i < E; ++i) {
-        xa[i] = xt[r][E * a + i];
-        ha[i] = (double)ht[r][E * a + i];
-        ra[i] = xa[i] - ha[i];
-        xb[i] = xt[r][E * b + i];
-        hb[i] = (double)ht[r][E * b + i];
-        rb[i] = xb[i] - hb[i];
-      }
-#pragma unroll
-      for (int i = 0; i < E; ++i)
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-          accA[i][j] = fma(ha[i], rb[j], fma(ra[i], xb[j], accA[i][j]));   // A(f = E a + i, g = E b + j)
-          accB[i][j] = fma(ha[i], rb[j], accB[i][j]);                      // Bt[g = E a + i][f = E b + j]
-        }
-      if (a == 0) {
-        const double yr = (double)yt[r];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-          vy[j] = fma(rb[j], yr, vy[j]);
-          v1[j] += rb[j];
-        }
-      }
-    }
+  const float cp = in ? hdr->colscale[p] : 0.f, cq = in ? hdr->colscale[q] : 0.f;
+  const double ip = cp > 0.f ? 1.0 / (double)cp : 0.0, iq = cq > 0.f ? 1.0 / (double)cq : 0.0;
+  const double a = (pq + qp) + rr;
+  gram[e] = (hh + a) * ip * iq;
+  low[e] = a * ip * iq;
+  low[4096 + e] = pq * ip * iq;
+  if (p < 2) {                                   // rows 0, 1 of the grid also carry the two vectors
+    double s = 0.0;
+    if (q < D)
+      for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * kSumStride + 3 * 4096 + 64 * p + q];
+    low[8192 + 64 * p + q] = s * (q < D ? iq0(hdr, q) : 0.0);
   }
-  double* out = lpart + (int64_t)blockIdx.x * kLowStride;
-#pragma unroll
-  for (int j = 0; j < E; ++j) {
-    const float csb = hdr->colscale[E * b + j];
-    const double invb = csb > 0.f ? 1.0 / (double)csb : 0.0;
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-      const float csa = hdr->colscale[E * a + i];
-      const double inva = csa > 0.f ? 1.0 / (double)csa : 0.0;
-      out[(E * a + i) * 64 + E * b + j] = accA[i][j] * inva * invb;
-      out[4096 + (E * a + i) * 64 + E * b + j] = accB[i][j] * inva * invb;
-    }
-    if (a == 0) {
-      out[8192 + E * b + j] = vy[j] * invb;
-      out[8192 + 64 + E * b + j] = v1[j] * invb;
-    }
-  }
-}
-
-// stage 2: fixed-order sum of the partials; entries beyond the model's features are zero
-__global__ void f16_low_final(const double* __restrict__ lpart, int nblk, int D, double* __restrict__ low) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= kLowStride) return;
-  const bool in = e < 8192 ? (((e & 4095) >> 6) < D && (e & 63) < D) : (((e - 8192) & 63) < D);
-  double s = 0.0;
-  if (in)
-    for (int b = 0; b < nblk; ++b) s += lpart[(int64_t)b * kLowStride + e];
-  low[e] = s;
 }
 
 // finalize, one workgroup of kFinGroups waves per chain: fixed-order reduction over row blocks in double (a wave
@@ -1378,7 +1475,7 @@ size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
 size_t bvi_linreg_f16_pack_scratch(int d) {
   const int dp = plane_cols(d);
   return (size_t)kStatBlocks * (dp + 2) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
-         (size_t)kGramBlocks * (64 * 64 + kLowStride) * sizeof(double) + 16;
+         (size_t)kGramBlocks * kSumStride * sizeof(double) + 16;
 }
 
 int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,
@@ -1390,8 +1487,7 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   const int64_t np = pad_rows(n);
   double* psum = (double*)scratch;
   double* gpart = psum + (size_t)kStatBlocks * (dp + 1);
-  double* lpart = gpart + (size_t)kGramBlocks * 64 * 64;
-  float* pmax = (float*)(lpart + (size_t)kGramBlocks * kLowStride);
+  float* pmax = (float*)(gpart + (size_t)kGramBlocks * kSumStride);
   double* gram = (double*)((unsigned char*)packed + kGramOffset);
   double* low = (double*)((unsigned char*)packed + kLowOffset);
   const int64_t total = np * (dp / 8);
@@ -1401,31 +1497,28 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   if (dp == 64) {
     hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
                        pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<64, false>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+    hipLaunchKernelGGL((f16_header_kernel<64, false>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
                        (const double*)psum, kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d,
                        (const float*)((const Header*)packed)->shift, pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<64, true>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+    hipLaunchKernelGGL((f16_header_kernel<64, true>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
                        (const double*)psum, kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
-    hipLaunchKernelGGL(f16_gram_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, (const Header*)packed, gpart);
-    hipLaunchKernelGGL(f16_low_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
+    hipLaunchKernelGGL(f16_sums_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, gpart);
   } else {
     hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
                        pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<32, false>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+    hipLaunchKernelGGL((f16_header_kernel<32, false>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
                        (const double*)psum, kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d,
                        (const float*)((const Header*)packed)->shift, pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<32, true>), dim3(1), dim3(64), 0, s, (const float*)pmax,
+    hipLaunchKernelGGL((f16_header_kernel<32, true>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
                        (const double*)psum, kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
-    hipLaunchKernelGGL(f16_gram_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, n, d, (const Header*)packed, gpart);
-    hipLaunchKernelGGL(f16_low_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, lpart);
+    hipLaunchKernelGGL(f16_sums_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, gpart);
   }
-  hipLaunchKernelGGL(f16_gram_final, dim3(16), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp, gram);
-  hipLaunchKernelGGL(f16_low_final, dim3((kLowStride + 255) / 256), dim3(256), 0, s, (const double*)lpart, kGramBlocks,
-                     dp, low);
+  hipLaunchKernelGGL(f16_sums_final, dim3(16), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp,
+                     (const Header*)packed, gram, low);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }

@@ -467,6 +467,33 @@ def test_linreg_deterministic(nat, ws, gpu_device):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+def test_linreg_pack_is_deterministic_and_its_sums_match_float64(nat, ws, gpu_device):
+    """The pack step (column statistics, f16 plane, and the pack-time sums X^T X, A = X^T X - XH^T XH, Bt = XH^T XR,
+    XR^T y, XR^T 1 behind the header, taken on the matrix cores as per-tile f32 sums added in double in a fixed order)
+    writes the same bytes on every run, for row counts that do and do not fill the last tile and for feature
+    counts below the plane's width; X^T X of the centred columns agrees with a float64 evaluation."""
+    rng = np.random.default_rng(77)
+    for n, d in ((70001, 64), (4096, 32), (12345, 50), (300, 20)):
+        X = (rng.normal(size=(n, d)) * 10.0 ** rng.uniform(-2, 2, d) + rng.normal(size=d)).astype(np.float32)
+        y = (X @ rng.normal(size=d) + rng.normal(size=n)).astype(np.float32)
+        Xd, yd = dev(X, gpu_device), dev(y, gpu_device)
+        a = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+        b = nat.linreg_pack(Xd, yd, fmt=nat.PACK_F16)
+        # (bytes 1040 .. 1279, between the header's fields and the sums, are never written)
+        assert torch.equal(a[:1040], b[:1040]) and torch.equal(a[1280:], b[1280:]), (n, d)
+        hdr = a[:1280 + 64 * 64 * 8].cpu().numpy()
+        shift = hdr[64 * 4 + 64 * 8 + 8 + 4 + 4:][:64 * 4].view(np.float32)[:d].astype(np.float64)
+        gram = hdr[1280:].view(np.float64).reshape(64, 64)
+        xc = X.astype(np.float64) - shift
+        ref = xc.T @ xc
+        scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))
+        # a tile sum of squares comes out of the f32 matrix instruction about one float ulp low (its accumulator is cut
+        # off, not rounded), the same way in every tile: ~1e-7 of X^T X's diagonal, which only ever multiplies the
+        # 2^-13-sized remainder of the weights
+        assert (np.abs(gram[:d, :d] - ref) / scale).max() <= 2.5e-7, (n, d, (np.abs(gram[:d, :d] - ref) / scale).max())
+        assert not gram[d:].any() and not gram[:, d:].any()
+
+
 def test_linreg_errors(nat, ws, gpu_device):
     X = torch.zeros(10, 65, device=gpu_device); y = torch.zeros(10, device=gpu_device)
     th = torch.ones(2, 67, device=gpu_device)
