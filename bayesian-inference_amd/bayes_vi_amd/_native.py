@@ -20,7 +20,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 108     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 109     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -109,6 +109,7 @@ def lib():
         l.bvi_advi_fullrank_sample.argtypes = [i32, i32, vp, vp, vp, vp, vp]
         l.bvi_advi_fullrank_grads.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         l.bvi_clip_adam_step.argtypes = [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, vp]
+        l.bvi_linreg_recommended_format.argtypes = [i64, i32, i32, ctypes.POINTER(ctypes.c_int)]
         l.bvi_philox_uint32.argtypes = [u64, u64, i32, i32, i32, vp, vp]
         l.bvi_philox_normal.argtypes = [u64, u64, i32, i32, vp, vp]
         for name in ('bvi_constrain', 'bvi_posterior_assemble', 'bvi_leapfrog_pre', 'bvi_leapfrog_post',
@@ -118,7 +119,7 @@ def lib():
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
                      'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
-                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_logp_rebase_shard', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads', 'bvi_advi_fullrank_sample',
+                     'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_logp_rebase_shard', 'bvi_linreg_recommended_format', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads', 'bvi_advi_fullrank_sample',
                      'bvi_advi_fullrank_grads',
                      'bvi_clip_adam_step'):
             getattr(l, name).restype = i32
@@ -233,6 +234,14 @@ def gmm1d_logp_grad(y, theta, k, ws: Workspace, want_grad=True, logp_ref=None):
     check(lib().bvi_gmm1d_logp_grad(_ptr(y), n, k, _ptr(theta), c, _ptr(logp), _ptr(grad), _ref_ptr(logp_ref),
                                     _ptr(buf), buf.numel(), _stream()), 'bvi_gmm1d_logp_grad')
     return logp, grad
+
+
+def linreg_recommended_format(n, d, n_chains):
+    """bvi_linreg_recommended_format: PACK_F16 when the packed f16-plane kernel is the route for this shape, else None."""
+    out = ctypes.c_int(-1)
+    check(lib().bvi_linreg_recommended_format(int(n), int(d), int(n_chains), ctypes.byref(out)),
+          'bvi_linreg_recommended_format')
+    return None if out.value < 0 else int(out.value)
 
 
 def linreg_pack(X, y, fmt=PACK_BF16X3):

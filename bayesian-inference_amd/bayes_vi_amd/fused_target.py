@@ -176,12 +176,9 @@ class LinearRegression(FusedLogLikelihood):
             return None
         if self.precision in (_native.PREC_BF16X3, _native.PREC_BF16X6):
             return _native.PACK_BF16X3 if self.d in (32, 64) else None
-        if self.precision != _native.PREC_AUTO or self.d > 64 or self.n < 16384:
+        if self.precision != _native.PREC_AUTO or self.d > 64:
             return None
-        few = 16 if self.d > 8 else 32
-        if c > few or (self.d > 8 and self.n >= 400_000):
-            return _native.PACK_F16
-        return None
+        return _native.linreg_recommended_format(self.n, self.d, c)      # the library's own rule (include/bvi.h)
 
     def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]

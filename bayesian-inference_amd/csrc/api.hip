@@ -66,6 +66,14 @@ int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes) {
   return BVI_OK;
 }
 
+int bvi_linreg_recommended_format(int64_t n, int d, int n_chains, int* format) {
+  if (!format || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (d < 1 || d > 64) return BVI_ERR_UNSUPPORTED;
+  const int few = d > 8 ? 16 : 32;
+  *format = (n >= 16384 && (n_chains > few || (d > 8 && n >= 400000))) ? BVI_PACK_F16 : -1;
+  return BVI_OK;
+}
+
 int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes) {
   if (!out_bytes) return BVI_ERR_ARG;
   if (format == BVI_PACK_F16 ? (d < 1 || d > 64) : (d != 32 && d != 64)) return BVI_ERR_UNSUPPORTED;

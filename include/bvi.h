@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 108
+#define BVI_VERSION 109
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -140,7 +140,8 @@ int bvi_normal_iid_logp_grad_noalloc(const float* y, int64_t n, const float* the
  * This entry point reads the caller's f32 matrix as it is and keeps nothing between calls.  A caller that
  * evaluates the same dataset many times (every sampler does) should pack it once with
  * bvi_linreg_pack(BVI_PACK_F16) and call bvi_linreg_packed_logp_grad: at n = 10M, d = 64, 1024 chains that is
- * 3.1 - 3.3 ms per evaluation against 8.2 ms here, and half the HBM traffic at few chains. */
+ * 3.0 ms per evaluation against 8.2 ms here, and half the HBM traffic at few chains; the pack step costs ~8 ms
+ * there.  bvi_linreg_recommended_format says, for a shape, whether packing is the faster route. */
 int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const float* theta,
                          int n_chains, int precision, float* logp, float* grad, const double* logp_ref,
                          void* ws, size_t ws_bytes, void* stream);
@@ -176,6 +177,15 @@ int bvi_linreg_logp_grad(const float* X, const float* y, int64_t n, int d, const
 #define BVI_PACK_BF16X3 0
 #define BVI_PACK_F16 1
 int bvi_linreg_packed_bytes(int64_t n, int d, int format, size_t* out_bytes);
+/* Which format a caller should pack a (shard of a) dataset into for evaluations of `n_chains` chains under
+ * BVI_PREC_AUTO: *format = BVI_PACK_F16 when the f16-plane kernel is the fastest route (more than 16 chains -- 32 for
+ * d <= 8 -- on at least 16384 rows, or any number of chains from 400 000 rows of more than 8 features on), or -1
+ * when bvi_linreg_logp_grad on the unpacked rows is (few chains on small shards; d > 64 is unsupported either
+ * way).  bvi_linreg_logp_grad itself never packs (it allocates nothing and the pack step is one pass over the
+ * data per dataset, not per call): with BVI_PREC_AUTO on unpacked rows and more than 16 chains it runs the
+ * slower bf16-piece kernel (n = 10M, d = 64, 1024 chains: 8.2 ms against 3.0 ms), so a caller that evaluates a
+ * dataset more than a few times asks here first.  No counterpart in the reference (TFP has one code path). */
+int bvi_linreg_recommended_format(int64_t n, int d, int n_chains, int* format);
 int bvi_linreg_pack_scratch_bytes(int d, int format, size_t* out_bytes);
 int bvi_linreg_pack(const float* X, const float* y, int64_t n, int d, int format, void* packed,
                     size_t packed_bytes, void* ws, size_t ws_bytes, void* stream);

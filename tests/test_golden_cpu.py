@@ -109,3 +109,11 @@ def test_library_exports_every_declared_symbol():
     assert lib.bvi_workspace_bytes(1, 100, 4, 65, 0, ctypes.byref(out)) == -2      # d > 64 unsupported
     assert lib.bvi_workspace_bytes(9, 100, 4, 1, 0, ctypes.byref(out)) == -2
     assert lib.bvi_workspace_bytes(0, -1, 4, 0, 0, ctypes.byref(out)) == -1
+    # which packed format to use is a host-side rule of the library (no GPU needed)
+    fmt = ctypes.c_int(7)
+    lib.bvi_linreg_recommended_format.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    for (n, d, c), want in (((10_000_000, 64, 1024), 1), ((10_000_000, 64, 1), 1), ((100_000, 64, 16), -1),
+                            ((100_000, 64, 17), 1), ((10_000, 64, 1024), -1), ((1_000_000, 8, 32), -1),
+                            ((1_000_000, 8, 33), 1), ((20_000, 32, 64), 1)):
+        assert lib.bvi_linreg_recommended_format(n, d, c, ctypes.byref(fmt)) == 0 and fmt.value == want, (n, d, c)
+    assert lib.bvi_linreg_recommended_format(100, 65, 4, ctypes.byref(fmt)) == -2
