@@ -33,6 +33,23 @@ def test_noalloc_entry_point_matches_workspace_entry_point(gpu_device):
         lp2 = torch.empty(c, device=gpu_device)
         st = lib.bvi_normal_iid_logp_grad_noalloc(nat._ptr(y), n, nat._ptr(th), c, nat._ptr(lp2), None, nat._stream())
         assert st == 0 and torch.equal(lp2, ref_lp)
+    # The counter above only sees torch's caching allocator.  Two checks that see the library's own calls: the
+    # device's free memory (hipMemGetInfo) is the same before and after a call, and a call recorded into a HIP graph
+    # -- where hipMalloc / hipFree are not permitted on the capturing stream -- captures and replays to the same result.
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    st = lib.bvi_normal_iid_logp_grad_noalloc(nat._ptr(y), n, nat._ptr(th), c, nat._ptr(lp), nat._ptr(gr), nat._stream())
+    torch.cuda.synchronize()
+    assert st == 0 and torch.cuda.mem_get_info()[0] == free_before
+    lp.fill_(float('nan')); gr.fill_(float('nan'))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = lib.bvi_normal_iid_logp_grad_noalloc(nat._ptr(y), n, nat._ptr(th), c, nat._ptr(lp), nat._ptr(gr),
+                                                  nat._stream())
+    assert st == 0
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lp, ref_lp) and torch.equal(gr, ref_g)
     # beyond the fixed scratch: a clear error, nothing launched
     c = nat.NOALLOC_MAX_CHAINS + 1
     th = torch.ones(c, 2, device=gpu_device)
