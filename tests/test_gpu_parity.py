@@ -616,6 +616,40 @@ def test_gmm_fullcov(nat, ws, gpu_device, d, k, c, n):
     np.testing.assert_array_equal(lp2.cpu().numpy(), lp.cpu().numpy())
 
 
+@pytest.mark.parametrize('d,k', [(8, 6), (32, 16)])
+def test_gmm_fullcov_rows_stored_cluster_by_cluster(nat, ws, gpu_device, d, k):
+    """Well-separated components, the rows once as drawn and once in the order the host layer stores them
+    (`cluster_row_order`: neighbouring rows from the same component).  In that order nearly every (component, 32-row
+    half) block of the raw-sums phase has no responsibility above 2^-40 and is skipped; both orders must give the
+    float64 oracle's sums -- including a component that owns no row at all and one chain whose components sit far
+    from the data (nothing is skipped for it)."""
+    from bayes_vi_amd.fused_target import cluster_row_order
+    rng = np.random.default_rng(31 * d + k)
+    n, c = 6000, 3
+    true_mu = rng.integers(-20, 21, (k, d)).astype(np.float64)
+    comp = rng.integers(0, k - 1, n)                       # the last component owns no row
+    Y = (true_mu[comp] + rng.normal(size=(n, d))).astype(np.float32)
+    w = rng.dirichlet(np.ones(k) * 5, c).astype(np.float32)
+    mu = (true_mu[None] + rng.normal(0, 0.2, (c, k, d))).astype(np.float32)
+    mu[2] += 3.0                                           # every row a few widths from every component of chain 2
+    L = np.tril(rng.normal(size=(c, k, d, d)) * 0.05)
+    for i in range(d):
+        L[..., i, i] = rng.uniform(0.9, 1.3, (c, k))
+    L = L.astype(np.float32)
+    theta = np.concatenate([w, mu.reshape(c, -1), L.reshape(c, -1)], -1)
+    ref_lp, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+    ref_g = np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
+    Yd = dev(Y, gpu_device)
+    order = cluster_row_order(Yd, k)
+    assert torch.equal(torch.sort(order).values, torch.arange(n, device=gpu_device))
+    changes = int((torch.tensor(comp, device=gpu_device)[order][1:] != torch.tensor(comp, device=gpu_device)[order][:-1]).sum())
+    assert changes < 8 * k                                 # the order does group the rows by component
+    for rows in (Yd, Yd[order].contiguous()):
+        lp, g = nat.gmm_fullcov_logp_grad(rows, dev(theta, gpu_device), k, ws)
+        assert_logp_close(lp.cpu().numpy(), ref_lp)
+        assert_grad_close(g.cpu().numpy(), ref_g, term_scale=np.full_like(ref_g, 3.0 * n))
+
+
 def test_logp_rebase_and_reference_level(nat, ws, gpu_device):
     """bvi_logp_rebase: the largest finite stored log-density becomes 0, the level takes it (split over the row
     shards), the absolute values come back, non-finite entries stay what they are; and a likelihood entry point
