@@ -13,6 +13,6 @@ PMC_COUNTERS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_S
 tools/chain_sweep.sh > "$OUT/r3_chain_sweep.txt" 2>&1
 { echo "# tools/gmm_bench.py, N = 100M, K = 8; rows in ascending order (what the host layer stores), then as drawn";
   timeout -k 10 200 python3 tools/gmm_bench.py --sorted --chains 1 2 3 4 16 64 1024;
-  timeout -k 10 200 python3 tools/gmm_bench.py --chains 1 4 16 64 1024; } > "$OUT/r3_mixture_output.txt" 2>&1
-{ timeout -k 10 120 python3 tools/fullcov_bench.py; timeout -k 10 120 python3 tools/fullcov_bench.py --clustered; } > "$OUT/r3_fullcov_output.txt" 2>&1
+  timeout -k 10 200 python3 tools/gmm_bench.py --chains 1 4 16 64 1024; } > "$OUT/r3_mixture_rows_ascending_output.txt" 2>&1
+{ timeout -k 10 120 python3 tools/fullcov_bench.py; timeout -k 10 120 python3 tools/fullcov_bench.py --clustered; } > "$OUT/r3_fullcov_clustered_output.txt" 2>&1
 ls -la "$OUT"
