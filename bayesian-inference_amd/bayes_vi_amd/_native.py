@@ -11,16 +11,17 @@ import os
 
 import torch
 
-FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV = 0, 1, 2, 3
+FAMILY_NORMAL_IID, FAMILY_LINREG, FAMILY_GMM1D, FAMILY_GMM_FULLCOV, FAMILY_MVN_TRIL = 0, 1, 2, 3, 4
+MVN_SCALE_TRIL, MVN_CHOL_PRECISION_SOLVE = 0, 1
 PREC_AUTO, PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 PACK_BF16X3, PACK_F16 = 0, 1
 
 BIJ_IDENTITY, BIJ_SOFTPLUS, BIJ_EXP, BIJ_SOFTMAX_CENTERED, BIJ_FILL_SCALE_TRIL = 0, 1, 2, 3, 4
-PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET = 0, 1, 2, 3
+PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET, PRIOR_WISHART_TRIL = 0, 1, 2, 3, 4
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 109     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 110     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -77,6 +78,7 @@ def lib():
         l.bvi_normal_iid_logp_grad_noalloc.restype = i32
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_mvn_tril_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_logp_rebase.argtypes = [i32, vp, i32, vp, vp, vp]
         l.bvi_logp_rebase_shard.argtypes = [i32, vp, ctypes.c_double, vp, vp, vp]
         l.bvi_linreg_packed_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]
@@ -118,7 +120,7 @@ def lib():
                      'bvi_nuts_subtree_begin', 'bvi_nuts_leaf', 'bvi_nuts_subtree_end'):
             getattr(l, name).restype = i32
         for name in ('bvi_workspace_bytes', 'bvi_normal_iid_logp_grad', 'bvi_linreg_logp_grad',
-                     'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
+                     'bvi_gmm1d_logp_grad', 'bvi_gmm_fullcov_logp_grad', 'bvi_mvn_tril_logp_grad', 'bvi_linreg_packed_bytes', 'bvi_linreg_pack', 'bvi_linreg_pack_scratch_bytes',
                      'bvi_linreg_packed_logp_grad', 'bvi_logp_rebase', 'bvi_logp_rebase_shard', 'bvi_linreg_recommended_format', 'bvi_advi_meanfield_sample', 'bvi_advi_meanfield_grads', 'bvi_advi_fullrank_sample',
                      'bvi_advi_fullrank_grads',
                      'bvi_clip_adam_step'):
@@ -305,4 +307,18 @@ def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True, logp_ref=N
     check(lib().bvi_gmm_fullcov_logp_grad(_ptr(Y), n, d, k, _ptr(theta), c, _ptr(logp), _ptr(grad),
                                           _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()),
           'bvi_gmm_fullcov_logp_grad')
+    return logp, grad
+
+
+def mvn_tril_logp_grad(Y, theta, parameterisation, ws: Workspace, want_grad=True, logp_ref=None):
+    """bvi_mvn_tril_logp_grad: Y[n, d], theta[C, d + d*d] = (loc, M) with M the scale (MVN_SCALE_TRIL) or a Cholesky
+    factor of the precision as the reference passes it (MVN_CHOL_PRECISION_SOLVE)."""
+    _check_f32_cuda(Y, theta)
+    n, d = Y.shape
+    c = theta.shape[0]
+    assert theta.shape == (c, d + d * d)
+    logp, grad = _outputs(theta, want_grad)
+    buf = ws.get(workspace_bytes(FAMILY_MVN_TRIL, n, c, d=d))
+    check(lib().bvi_mvn_tril_logp_grad(_ptr(Y), n, d, int(parameterisation), _ptr(theta), c, _ptr(logp), _ptr(grad),
+                                       _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()), 'bvi_mvn_tril_logp_grad')
     return logp, grad

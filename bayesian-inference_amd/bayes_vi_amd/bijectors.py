@@ -122,8 +122,28 @@ class FillScaleTriL(Bijector):
     With `batch` = B the flat vector holds B such blocks back to back ([B, D(D+1)/2] ->
     [B, D, D] flattened): a parameter like scale_tril[K, D, D] of a mixture."""
 
-    def __init__(self, d, diag_shift=1e-5, batch=1):
+    def __init__(self, d=None, diag_shift=1e-5, batch=1, diag_bijector=None):
+        if diag_bijector is not None and not isinstance(diag_bijector, Softplus):
+            raise NotImplementedError('FillScaleTriL: only diag_bijector=Softplus() is implemented')
         self.d, self.diag_shift, self.batch = d, diag_shift, batch
+        if d is not None:
+            self._build()
+
+    def bind(self, event_shape):
+        """TFP infers the matrix size from its input; written without `d` (tfb.FillScaleTriL(diag_bijector=...,
+        diag_shift=...), multivariate-gaussian-test.ipynb cell 15) the size comes from the parameter's event shape
+        [..., D, D] when the model is built."""
+        if self.d is None:
+            shape = tuple(event_shape)
+            if len(shape) < 2 or shape[-1] != shape[-2]:
+                raise ValueError('FillScaleTriL constrains [..., D, D] parameters; got event shape %s' % (shape,))
+            self.d = int(shape[-1])
+            self.batch = int(math.prod(shape[:-2])) if len(shape) > 2 else 1
+            self._build()
+        return self
+
+    def _build(self):
+        d, batch = self.d, self.batch
         full = fill_triangular_index(d)
         rows, cols = torch.tril_indices(d, d)
         m, dd = d * (d + 1) // 2, d * d

@@ -225,10 +225,75 @@ class MultivariateNormalDiag(Distribution):
 
     log_prob_flat = log_prob
 
+    def score_flat(self, x):
+        sc = _on(self.scale_diag, x.device)
+        return -(x - _on(self.loc, x.device)) / (sc * sc)
+
     def sample(self, sample_shape=(), generator=None):
         shape = tuple(sample_shape) + tuple(torch.broadcast_shapes(self.loc.shape, self.scale_diag.shape))
         eps = torch.randn(shape, generator=generator).to(self.loc.device)
         return self.loc + self.scale_diag * eps
+
+
+class WishartTriL(Distribution):
+    """tfd.WishartTriL(df, scale_tril, input_output_cholesky=True): a Wishart(df, V = S S^T) matrix handled through
+    its Cholesky factor L (exploratory_experiments/multivariate-gaussian-test.ipynb cell 15).  `log_prob(L)` is the
+    Wishart log density of L L^T -- TFP adds no Jacobian term for L -> L L^T -- and `sample` returns Cholesky
+    factors.  Only the Cholesky form is implemented."""
+
+    def __init__(self, df, scale_tril, input_output_cholesky=False, name='WishartTriL'):
+        if not input_output_cholesky:
+            raise NotImplementedError('WishartTriL is implemented for input_output_cholesky=True only')
+        self.df, self.name = float(df), name
+        self.scale_tril = torch.tril(_t(scale_tril).to(torch.float32))
+        self.d = int(self.scale_tril.shape[-1])
+        if self.scale_tril.dim() != 2 or self.df <= self.d - 1:
+            raise ValueError('WishartTriL needs one [D, D] scale_tril and df > D - 1')
+        s64 = self.scale_tril.double()
+        self._vinv = torch.cholesky_inverse(s64).float()                      # (S S^T)^-1
+        d, df = self.d, self.df
+        self._lognorm = float(0.5 * df * d * math.log(2.0) + df * torch.log(torch.diagonal(s64)).sum()
+                              + 0.25 * d * (d - 1) * math.log(math.pi)
+                              + sum(math.lgamma(0.5 * (df - m)) for m in range(d)))
+
+    @property
+    def event_shape(self):
+        return torch.Size((self.d, self.d))
+
+    def isotropic_scale(self):
+        """s if scale_tril = s I, else None."""
+        s = float(self.scale_tril[0, 0])
+        return s if s > 0 and bool((self.scale_tril == s * torch.eye(self.d)).all()) else None
+
+    def log_prob(self, x):
+        return self.log_prob_flat(x.reshape(x.shape[:-2] + (self.d * self.d,)))
+
+    def log_prob_flat(self, x):
+        d = self.d
+        L = torch.tril(x.reshape(x.shape[:-1] + (d, d)))
+        vinv = _on(self._vinv, x.device).to(x.dtype)
+        tr = ((vinv @ L) * L).sum((-2, -1))
+        half_log_det = torch.log(torch.diagonal(L, dim1=-2, dim2=-1)).sum(-1)
+        return (self.df - d - 1.0) * half_log_det - 0.5 * tr - self._lognorm
+
+    def score_flat(self, x):
+        d = self.d
+        L = torch.tril(x.reshape(x.shape[:-1] + (d, d)))
+        vinv = _on(self._vinv, x.device).to(x.dtype)
+        g = -(vinv @ L) + torch.diag_embed((self.df - d - 1.0) / torch.diagonal(L, dim1=-2, dim2=-1))
+        return torch.tril(g).reshape(x.shape)
+
+    def sample(self, sample_shape=(), generator=None):
+        """Bartlett: L = S A, A lower triangular with A_ii^2 ~ chi^2(df - i) and standard normals below."""
+        shape = tuple(sample_shape)
+        d = self.d
+        a = torch.tril(torch.randn(shape + (d, d), generator=generator), -1)
+        conc = torch.tensor([0.5 * (self.df - i) for i in range(d)]).expand(shape + (d,))
+        chi = torch.sqrt(2.0 * torch._standard_gamma(conc))
+        return self.scale_tril @ (a + torch.diag_embed(chi))
+
+    def default_bijector(self):
+        return tfb.FillScaleTriL(self.d)
 
 
 class MixtureSameFamily(Distribution):

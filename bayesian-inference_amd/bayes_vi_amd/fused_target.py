@@ -280,6 +280,27 @@ class GaussianMixtureFullCov(FusedLogLikelihood):
                 buf.numel(), _native._stream())
 
 
+class MultivariateNormalTriL(FusedLogLikelihood):
+    """y_i ~ N(loc, S S^T); theta = (loc[D], M[D, D]) with S = tril(M) (`MVN_SCALE_TRIL`) or, for
+    `MVN_CHOL_PRECISION_SOLVE`, S = tril((M M^T)^-1): what MultivariateNormalTriL(loc, scale_tril=
+    cholesky_solve(M, eye)) evaluates.  exploratory_experiments/multivariate-gaussian-test.ipynb cell 15."""
+    family = _native.FAMILY_MVN_TRIL
+
+    def __init__(self, Y, parameterisation=_native.MVN_SCALE_TRIL, group=None):
+        super().__init__(Y.device, group)
+        self.Y = Y.to(torch.float32).contiguous()
+        self.n, self.d = self.Y.shape
+        self.parameterisation = int(parameterisation)
+        self.n_params = self.d + self.d * self.d
+
+    def _call(self, theta, logp, grad, relative=False):
+        c = theta.shape[0]
+        buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d))
+        _launch(_native.lib().bvi_mvn_tril_logp_grad, _native._ptr(self.Y), self.n, self.d, self.parameterisation,
+                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf),
+                buf.numel(), _native._stream())
+
+
 class Posterior:
     """log pi(theta) = log-likelihood (fused) + sum of log-priors, in constrained
     and unconstrained coordinates.
@@ -326,6 +347,13 @@ class Posterior:
                 spec = (_native.PRIOR_HALFNORMAL, scalar(prior.scale), 0.0)
             elif isinstance(prior, _dist.Dirichlet):
                 spec = (_native.PRIOR_DIRICHLET, scalar(prior.concentration), 0.0)
+            elif isinstance(prior, _dist.MultivariateNormalDiag):
+                spec = (_native.PRIOR_NORMAL, scalar(prior.loc), scalar(prior.scale_diag))
+            elif isinstance(prior, _dist.WishartTriL):
+                # the device prior covers scale_tril = s I (what the reference's model uses); others go through torch
+                spec = (_native.PRIOR_WISHART_TRIL, float(prior.df), prior.isotropic_scale())
+                if not isinstance(bij, _bij.FillScaleTriL) or bij.d != prior.d:
+                    spec = (None, None, None)
             else:
                 spec = (None, None, None)
             if spec[0] is None or spec[1] is None or spec[2] is None:

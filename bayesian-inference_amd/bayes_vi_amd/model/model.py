@@ -19,7 +19,7 @@ from .. import bijectors as tfb
 from .. import distributions as tfd
 from .. import symbolic as sym
 from ..fused_target import (FusedLogLikelihood, GaussianMixture1D, GaussianMixtureFullCov, LinearRegression,
-                            NormalIID, Posterior, ShardedLogLikelihood)
+                            MultivariateNormalTriL, NormalIID, Posterior, ShardedLogLikelihood)
 from ..utils import to_ordered_dict
 
 
@@ -120,6 +120,9 @@ class Model:
         self.joint_constraining_bijector = self.constraining_bijectors   # applied part-wise
 
         self.param_event_shape = [p.param_event_shape() for p in self.priors.values()]
+        for b, shape in zip(self.constraining_bijectors, self.param_event_shape):
+            if hasattr(b, 'bind'):
+                b.bind(shape)
         block_sizes = [_prod(s) for s in self.param_event_shape]
         unconstrained_block_sizes = [b.inverse_event_size(n) for b, n in zip(self.constraining_bijectors, block_sizes)]
         self.unconstrained_param_event_shape = [
@@ -161,7 +164,7 @@ class Model:
 
     def describe_likelihood(self, features=None):
         """Symbolic recognition only (no data touched, no GPU): returns a dict with
-        'family' in {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov'}, 'index' (kernel parameter j <- model flat
+        'family' in {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov', 'mvn_tril'}, 'index' (kernel parameter j <- model flat
         index, -1 = constant 0) and, for 'linreg', the design-column recipe:
         'columns' = [[(feature_key, coef), ...] per slope parameter] and 'offset' =
         [(feature_key | None, coef), ...] terms to subtract from y."""
@@ -228,8 +231,21 @@ class Model:
                 return dict(family='gmm_fullcov', k=k, d=d, index=index)
             raise sym.UnsupportedLikelihood('only mixtures of Normal(loc[K], scale[K]) or of '
                                             'MultivariateNormalTriL(loc[K, D], scale_tril[K, D, D]) are fused')
+        if isinstance(dist, tfd.MultivariateNormalTriL):
+            if not sym.is_plain_param(dist.loc):
+                raise sym.UnsupportedLikelihood('MultivariateNormalTriL likelihood: `loc` must be one vector parameter')
+            d = dist.loc.size
+            mat, mode = dist.scale_tril, 'scale_tril'
+            if isinstance(mat, sym.CholeskySolveIdentity):
+                mat, mode = mat.param, 'cholesky_solve_identity'
+            if not sym.is_plain_param(mat, d * d) or not self.is_generative_model:
+                raise sym.UnsupportedLikelihood('MultivariateNormalTriL likelihood: scale_tril must be one [D, D] '
+                                                'parameter or linalg.cholesky_solve(<[D, D] parameter>, linalg.eye(D))')
+            index = [off[dist.loc.name] + j for j in range(d)] + [off[mat.name] + j for j in range(d * d)]
+            return dict(family='mvn_tril', d=d, parameterisation=mode, index=index)
         raise sym.UnsupportedLikelihood('likelihood %s is not one of the fused families '
-                                        '(Normal, Normal linear regression, MixtureSameFamily of Normal)'
+                                        '(Normal, Normal linear regression, MixtureSameFamily of Normal or of '
+                                        'MultivariateNormalTriL, MultivariateNormalTriL)'
                                         % type(dist).__name__)
 
     def design_matrix(self, desc, features, targets):
@@ -266,6 +282,9 @@ class Model:
             inner = GaussianMixture1D(self._to_device(y), desc['k'], group=group)
         elif desc['family'] == 'gmm_fullcov':
             inner = GaussianMixtureFullCov(self._to_device(y.reshape(-1, desc['d'])), desc['k'], group=group)
+        elif desc['family'] == 'mvn_tril':
+            mode = _native.MVN_SCALE_TRIL if desc['parameterisation'] == 'scale_tril' else _native.MVN_CHOL_PRECISION_SOLVE
+            inner = MultivariateNormalTriL(self._to_device(y.reshape(-1, desc['d'])), mode, group=group)
         else:
             X, y_adj = self.design_matrix(desc, features, y)
             inner = LinearRegression(self._to_device(X), self._to_device(y_adj), group=group,

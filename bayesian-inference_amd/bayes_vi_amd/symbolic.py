@@ -164,6 +164,15 @@ def matvec(features, w):
     return Affine([((w.name, j if w.size > 1 else None), features.keys[j], 1.0) for j in range(w.size)])
 
 
+class CholeskySolveIdentity:
+    """(P P^T)^-1 for a whole [D, D] parameter P: what `linalg.cholesky_solve(P, linalg.eye(D))` returns on a
+    symbolic parameter."""
+
+    def __init__(self, param):
+        self.param = param
+        self.size = param.size
+
+
 def is_plain_param(v, size=None):
     """v is exactly one whole parameter (optionally of the given size)."""
     if isinstance(v, ParamSym) and v.index is None:

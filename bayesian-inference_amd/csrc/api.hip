@@ -34,6 +34,10 @@ int bvi_workspace_bytes(int family, int64_t n_rows, int n_chains, int d, int k, 
       if (k < 1 || k > 16 || d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
       *out_bytes = bvi_ws_gmm_fullcov(n_rows, n_chains, d, k);
       break;
+    case BVI_FAMILY_MVN_TRIL:
+      if (d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+      *out_bytes = bvi_ws_mvn_tril(n_rows, n_chains, d);
+      break;
     default: return BVI_ERR_UNSUPPORTED;
   }
   return BVI_OK;
@@ -133,6 +137,17 @@ int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const flo
   if (!ws || ws_bytes < bvi_ws_gmm_fullcov(n, n_chains, d, k)) return BVI_ERR_WORKSPACE;
   return bvi_launch_gmm_fullcov(Y, n, d, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream,
                                 logp_ref);
+}
+
+int bvi_mvn_tril_logp_grad(const float* Y, int64_t n, int d, int parameterisation, const float* theta, int n_chains,
+                           float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
+                           void* stream) {
+  if ((!Y && n > 0) || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (parameterisation != BVI_MVN_SCALE_TRIL && parameterisation != BVI_MVN_CHOL_PRECISION_SOLVE) return BVI_ERR_ARG;
+  if (d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < bvi_ws_mvn_tril(n, n_chains, d)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_mvn_tril(Y, n, d, parameterisation, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream,
+                             logp_ref);
 }
 
 }  // extern "C"

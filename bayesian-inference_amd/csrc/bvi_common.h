@@ -53,6 +53,9 @@ int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* 
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
                            float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k);
+int bvi_launch_mvn_tril(const float* Y, int64_t n, int d, int mode, const float* theta, int c, float* logp,
+                        float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
+size_t bvi_ws_mvn_tril(int64_t n, int c, int d);
 
 size_t bvi_linreg_f16_packed_size(int64_t n, int d);
 size_t bvi_linreg_f16_pack_scratch(int d);

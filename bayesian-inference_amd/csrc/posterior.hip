@@ -55,6 +55,28 @@ __device__ __forceinline__ float prior_elem(const bvi_param_block& b, int j, flo
     *score = (b.a - 1.f) / th;
     return (b.a - 1.f) * logf(th) + (j == 0 ? lgammaf(b.a * b.size) - b.size * lgammaf(b.a) : 0.f);
   }
+  if (b.prior == BVI_PRIOR_WISHART_TRIL) {
+    // log Wishart(L L^T; df = a, V = b^2 I) for a Cholesky factor L, no Jacobian of L -> L L^T (TFP's
+    // input_output_cholesky=True):  (a - d - 1) sum_i log L_ii - |L|_F^2 / (2 b^2) - log Z, element by element;
+    // log Z = a d log b + a d log(2) / 2 + d (d - 1) log(pi) / 4 + sum_{m < d} lgamma((a - m) / 2), once per matrix
+    const int d = b.dim, f = j % (d * d), row = f / d, col = f - row * d;
+    float lp = 0.f;
+    *score = 0.f;
+    if (col <= row) {
+      lp = -0.5f * th * th / (b.b * b.b);
+      *score = -th / (b.b * b.b);
+      if (col == row) {
+        lp += (b.a - (float)d - 1.f) * logf(th);
+        *score += (b.a - (float)d - 1.f) / th;
+      }
+    }
+    if (f == 0) {
+      float z = b.a * (float)d * (logf(b.b) + 0.5f * 0.69314718056f) + 0.25f * (float)(d * (d - 1)) * 1.1447298858f;
+      for (int m = 0; m < d; ++m) z += lgammaf(0.5f * (b.a - (float)m));
+      lp -= z;
+    }
+    return lp;
+  }
   *score = 0.f;
   return 0.f;
 }

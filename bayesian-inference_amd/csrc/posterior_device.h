@@ -188,7 +188,9 @@ inline int make_blocks(const bvi_param_block* blocks, int n_blocks, Blocks* out,
   for (int i = 0; i < n_blocks; ++i) {
     const bvi_param_block b = blocks[i];
     if (b.size < 1 || b.bijector < BVI_BIJ_IDENTITY || b.bijector > BVI_BIJ_FILL_SCALE_TRIL ||
-        b.prior < BVI_PRIOR_NONE || b.prior > BVI_PRIOR_DIRICHLET)
+        b.prior < BVI_PRIOR_NONE || b.prior > BVI_PRIOR_WISHART_TRIL)
+      return BVI_ERR_ARG;
+    if (b.prior == BVI_PRIOR_WISHART_TRIL && (b.bijector != BVI_BIJ_FILL_SCALE_TRIL || !(b.a > (float)(b.dim - 1)) || !(b.b > 0.f)))
       return BVI_ERR_ARG;
     if (b.bijector == BVI_BIJ_SOFTMAX_CENTERED && b.size < 2) return BVI_ERR_ARG;
     if (b.bijector == BVI_BIJ_FILL_SCALE_TRIL) {

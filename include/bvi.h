@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 109
+#define BVI_VERSION 110
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -61,6 +61,12 @@ extern "C" {
 #define BVI_FAMILY_LINREG 1       /* tfd.Normal(beta_0 + X w, scale)                    README.md:747-756 */
 #define BVI_FAMILY_GMM1D 2        /* MixtureSameFamily(Categorical(probs), Normal)      univariate-gaussian-mixture-test.ipynb cell 15 */
 #define BVI_FAMILY_GMM_FULLCOV 3  /* MixtureSameFamily(Categorical, MultivariateNormalTriL)  ...density-estimation-test.ipynb cell 7 */
+#define BVI_FAMILY_MVN_TRIL 4     /* MultivariateNormalTriL(loc, scale_tril)            multivariate-gaussian-test.ipynb cell 15 */
+
+/* what the matrix parameter of BVI_FAMILY_MVN_TRIL is */
+#define BVI_MVN_SCALE_TRIL 0            /* the scale S itself (lower triangle read)                               */
+#define BVI_MVN_CHOL_PRECISION_SOLVE 1  /* a Cholesky factor P of the precision; S = tril((P P^T)^-1): what
+                                           scale_tril = tf.linalg.cholesky_solve(P, eye) evaluates                 */
 
 /* arithmetic of the chains x features x rows contraction (linear regression) */
 #define BVI_PREC_AUTO 0           /* bvi_linreg_logp_grad (unpacked f32 X): BF16X6 when n_chains >= 128,
@@ -89,6 +95,9 @@ extern "C" {
 #define BVI_PRIOR_NORMAL 1          /* Normal(loc = a, scale = b) on every element        */
 #define BVI_PRIOR_HALFNORMAL 2      /* HalfNormal(scale = a) on every element             */
 #define BVI_PRIOR_DIRICHLET 3       /* Dirichlet(concentration = a on all `size` entries) */
+#define BVI_PRIOR_WISHART_TRIL 4    /* WishartTriL(df = a, scale_tril = b * I, input_output_cholesky=True) on every
+                                       [dim, dim] Cholesky factor of a FILL_SCALE_TRIL block
+                                       (multivariate-gaussian-test.ipynb cell 15)                          */
 
 /* One entry of Model.priors / Model.constraining_bijectors (bayes_vi/model/model.py:106-116),
  * in param_names order.  `size` is the flat constrained size of the block. */
@@ -214,6 +223,17 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
 int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
                               float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
                               void* stream);
+
+/* Single multivariate normal: Y[n,d] row-major, theta[C, d + d*d] = (loc[d], M[d][d] row-major, entries above the
+ * diagonal ignored) -> logp[C], grad[C, same layout] (gradient of M lower triangular).  `parameterisation` says
+ * what M is (BVI_MVN_*).  d <= 32.  The sum over the rows is the one-component case of the full-covariance mixture
+ * kernels; the maps M -> scale and d/d scale -> d/d M run per chain in double precision.
+ * Workspace: bvi_workspace_bytes(BVI_FAMILY_MVN_TRIL, n, C, d, 0).
+ * Replaces the likelihood node MultivariateNormalTriL(loc, scale_tril=cholesky_solve(precision, eye)) of
+ * exploratory_experiments/multivariate-gaussian-test.ipynb cell 15 and its gradient. */
+int bvi_mvn_tril_logp_grad(const float* Y, int64_t n, int d, int parameterisation, const float* theta, int n_chains,
+                           float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ---- device-side posterior assembly: what tfp.mcmc.TransformedTransitionKernel adds around the
  * target closure (bayes_vi/inference/mcmc/mcmc.py:153-156).  `blocks` is a HOST array.  With

@@ -10,6 +10,11 @@ closed forms instead (tests/test_oracle_pins.py, tests/test_host_logic.py):
                        finite differences;
   gmm1d, gmm_fullcov : scipy.stats / torch.distributions and finite differences only -- the reference
                        holds no table or fixture for the mixtures: PARITY UNPINNED for these two.
+  mvn_chol_precision, wishart_tril_prior : scipy.stats (multivariate_normal, wishart) and finite differences; the
+                       notebook prints one posterior summary of a 1000-step flow fit on data it does not keep:
+                       PARITY UNPINNED.  How TFP reads the arguments (WishartTriL's log_prob of a Cholesky factor
+                       without a Jacobian term; MultivariateNormalTriL using the lower triangle of a full matrix)
+                       is recalled TFP 0.12 behaviour.
 
 What the reference computes on this path
 ----------------------------------------
@@ -36,6 +41,8 @@ mcmc.py:83-99 / model.py:123-153):
     gmm1d      : theta[C, 3K]    = [weights_K, loc_K, scale_K] (univariate-gaussian-mixture-test.ipynb cell 15)
     gmm_fullcov: theta[C, K+K*D+K*D*D] = [weights_K, locs_KxD, scale_tril_KxDxD]
                  (multivariate-gaussian-mixture-density-estimation-test.ipynb cell 7)
+    mvn_chol_precision: theta[C, D+D*D] = [loc_D, precision-Cholesky_DxD]
+                 (multivariate-gaussian-test.ipynb cell 15)
 """
 from __future__ import annotations
 
@@ -75,6 +82,29 @@ def dirichlet_prior(w, concentration):
     norm = gammaln(a.sum(-1)) - gammaln(a).sum(-1)
     lp = norm + ((a - 1.0) * np.log(w)).sum(-1)
     return lp, (a - 1.0) / w
+
+
+def wishart_tril_prior(x, df, scale_tril):
+    """tfd.WishartTriL(df, scale_tril, input_output_cholesky=True).log_prob of Cholesky factors
+    (multivariate-gaussian-test.ipynb cell 15).  x[..., D*D]: lower-triangular L, row-major; the value is the
+    Wishart log density of X = L L^T with V = S S^T,
+        (df - D - 1) sum_i log L_ii - |S^-1 L|_F^2 / 2 - [df D log(2) / 2 + df sum_i log S_ii + log Gamma_D(df / 2)],
+    with no Jacobian term for L -> X (recalled TFP behaviour).  Returns (lp[...], d lp / d x[..., D*D]) with the
+    derivative taken entry by entry of the lower triangle (zero above it)."""
+    x, S = _f64(x), _f64(scale_tril)
+    d = S.shape[-1]
+    L = x.reshape(x.shape[:-1] + (d, d))
+    Vinv = np.linalg.inv(S @ S.T)
+    diag = np.diagonal(L, axis1=-2, axis2=-1)
+    tr = np.einsum('...ij,ik,...kj->...', L, Vinv, L)
+    lognorm = (0.5 * df * d * math.log(2.0) + df * np.log(np.diag(S)).sum() + 0.25 * d * (d - 1) * math.log(math.pi)
+               + sum(gammaln(0.5 * (df - m)) for m in range(d)))
+    lp = (df - d - 1.0) * np.log(diag).sum(-1) - 0.5 * tr - lognorm
+    g = -np.einsum('ik,...kj->...ij', Vinv, L)
+    idx = np.arange(d)
+    g[..., idx, idx] += (df - d - 1.0) / diag
+    g = np.tril(g)
+    return lp, g.reshape(x.shape)
 
 
 # --------------------------------------------------------------------------
@@ -171,6 +201,35 @@ def gmm_fullcov(Y, weights, locs, tril):
             g = m - rho[ki].sum() * np.diag(1.0 / np.diag(L[ci, ki]))
             g_L[ci, ki] = np.tril(g)
     return logp, (g_w, g_mu, g_L)
+
+
+def mvn_chol_precision(Y, theta):
+    """MultivariateNormalTriL(loc, scale_tril=cholesky_solve(P, eye)) (multivariate-gaussian-test.ipynb cell 15).
+
+    Y[N,D], theta[C, D+D*D] = (loc, P row-major, lower triangular) -> logp[C], grad[C, D+D*D].
+    cholesky_solve(P, I) is the full matrix Sigma = (P P^T)^-1 and MultivariateNormalTriL reads the lower triangle of
+    what it is given (recalled TFP behaviour), so the scale is S = tril(Sigma).  Gradient: with G = d logp / d S,
+    d logp / d P = -tril(Sigma (G + G^T) Sigma P)."""
+    Y, theta = _f64(Y), _f64(theta)
+    n, d = Y.shape
+    c = theta.shape[0]
+    loc, P = theta[:, :d], np.tril(theta[:, d:].reshape(c, d, d))
+    Sigma = np.linalg.inv(P @ np.swapaxes(P, -1, -2))
+    S = np.tril(Sigma)
+    logp, (_, g_mu, g_S) = gmm_fullcov(Y, np.ones((c, 1)), loc[:, None, :], S[:, None])
+    G = g_S[:, 0]
+    gP = -np.tril(Sigma @ (G + np.swapaxes(G, -1, -2)) @ Sigma @ P)
+    return logp, np.concatenate([g_mu[:, 0], gP.reshape(c, d * d)], -1)
+
+
+def mvn_scale_tril(Y, theta):
+    """MultivariateNormalTriL(loc, scale_tril): Y[N,D], theta[C, D+D*D] = (loc, scale_tril) -> logp, grad."""
+    Y, theta = _f64(Y), _f64(theta)
+    n, d = Y.shape
+    c = theta.shape[0]
+    loc, S = theta[:, :d], np.tril(theta[:, d:].reshape(c, d, d))
+    logp, (_, g_mu, g_S) = gmm_fullcov(Y, np.ones((c, 1)), loc[:, None, :], S[:, None])
+    return logp, np.concatenate([g_mu[:, 0], g_S[:, 0].reshape(c, d * d)], -1)
 
 
 # --------------------------------------------------------------------------
@@ -284,7 +343,8 @@ class ModelSpec:
 
     blocks: list of dicts, in ``param_names`` order:
         {'name', 'size' (constrained flat size), 'prior': ('normal', loc, scale) |
-         ('halfnormal', scale) | ('dirichlet', conc[K]), 'bijector': instance}
+         ('halfnormal', scale) | ('dirichlet', conc[K]) | ('wishart_tril', df, scale_tril[D,D]),
+         'bijector': instance}
     likelihood: callable theta[C,P] -> (logp[C], grad[C,P]) in constrained space.
     """
 
@@ -326,6 +386,8 @@ class ModelSpec:
                 l, d = halfnormal_prior(x, b['prior'][1]); l = l.sum(-1)
             elif kind == 'dirichlet':
                 l, d = dirichlet_prior(x, b['prior'][1])
+            elif kind == 'wishart_tril':
+                l, d = wishart_tril_prior(x, b['prior'][1], b['prior'][2])
             else:
                 raise ValueError(kind)
             lp += l; g[:, o:o + b['size']] = d; o += b['size']
@@ -376,3 +438,14 @@ def gmm1d_model(y, k, prior_sd=10.0, prior_scale=10.0):
               dict(name='loc', size=k, prior=('normal', 0.0, prior_sd), bijector=Identity()),
               dict(name='scale', size=k, prior=('halfnormal', prior_scale), bijector=Softplus())]
     return ModelSpec(blocks, lambda th: gmm1d(y, th, k))
+
+
+def mvn_chol_precision_model(Y, df=5.0, prior_sd=10.0, wishart_scale=10.0, diag_shift=1e-3):
+    """multivariate-gaussian-test.ipynb cell 15: loc ~ MultivariateNormalDiag(0, 10), precision ~
+    WishartTriL(df=5, scale_tril=10 I, input_output_cholesky=True), bijectors Identity and
+    FillScaleTriL(Softplus, diag_shift=1e-3)."""
+    d = np.asarray(Y).shape[1]
+    blocks = [dict(name='loc', size=d, prior=('normal', 0.0, prior_sd), bijector=Identity()),
+              dict(name='precision', size=d * d, prior=('wishart_tril', df, wishart_scale * np.eye(d)),
+                   bijector=FillScaleTriL(d, diag_shift))]
+    return ModelSpec(blocks, lambda th: mvn_chol_precision(Y, th))

@@ -68,6 +68,18 @@ def main():
     grad = np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
     cases.append(dict(family='gmm_fullcov', k=k, d=d, Y=Y.tolist(), theta=theta.tolist(), logp=lp.tolist(),
                       grad=grad.tolist()))
+    # single multivariate normal whose scale is given through a Cholesky factor of the precision
+    # (multivariate-gaussian-test.ipynb cell 15): D = 3, 2 chains; theta flat = (loc[D], P[D, D]) row-major
+    d, c, n = 3, 2, 40
+    A = np.tril(rng.normal(size=(d, d)) * 0.4) + np.eye(d)
+    Y = r32(1.0 + rng.normal(size=(n, d)) @ A.T)
+    P = np.tril(rng.normal(size=(c, d, d)) * 0.15)
+    for i in range(d):
+        P[:, i, i] = rng.uniform(0.6, 1.4, c)
+    theta = r32(np.concatenate([rng.normal(1.0, 0.3, (c, d)), P.reshape(c, -1)], -1))
+    lp, grad = cf.mvn_chol_precision(Y, theta)
+    cases.append(dict(family='mvn_tril', parameterisation='cholesky_solve_identity', d=d, Y=Y.tolist(),
+                      theta=theta.tolist(), logp=lp.tolist(), grad=grad.tolist()))
     out = os.path.join(os.path.dirname(__file__), 'hotpath_small.json')
     with open(out, 'w') as f:
         json.dump(dict(note='closed-form fp64 oracle outputs on float32 inputs; not TFP outputs', cases=cases), f)

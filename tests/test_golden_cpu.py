@@ -31,6 +31,8 @@ def run_oracle(case):
         w, mu, L = th[:, :k], th[:, k:k + k * d].reshape(c, k, d), th[:, k + k * d:].reshape(c, k, d, d)
         lp, (gw, gmu, gL) = cf.gmm_fullcov(np.asarray(case['Y'], np.float32), w, mu, L)
         return lp, np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
+    if case['family'] == 'mvn_tril':
+        return cf.mvn_chol_precision(np.asarray(case['Y'], np.float32), th)
     return cf.gmm1d(np.asarray(case['y'], np.float32), th, case['k'])
 
 
@@ -42,7 +44,7 @@ def test_oracle_reproduces_golden():
 
 
 def test_golden_covers_every_likelihood_family():
-    assert {c['family'] for c in load_cases()} == {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov'}
+    assert {c['family'] for c in load_cases()} == {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov', 'mvn_tril'}
 
 
 def test_oracle_reproduces_golden_advi_step():
@@ -73,7 +75,7 @@ def test_oracle_reproduces_golden_advi_step():
 
 def test_restated_torch_reproduces_golden():
     for case in load_cases():
-        if case['family'] == 'gmm_fullcov':
+        if case['family'] in ('gmm_fullcov', 'mvn_tril'):
             continue                     # the restated torch path covers the three families it is timed on
         th = torch.tensor(case['theta'], dtype=torch.float32)
         y = torch.tensor(case['y'], dtype=torch.float32)

@@ -35,7 +35,7 @@ def dev(a, device):
 def test_golden_vectors(nat, ws, gpu_device):
     with open(os.path.join(ROOT, 'tests', 'golden', 'hotpath_small.json')) as f:
         cases = json.load(f)['cases']
-    assert {c['family'] for c in cases} == {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov'}
+    assert {c['family'] for c in cases} == {'normal_iid', 'linreg', 'gmm1d', 'gmm_fullcov', 'mvn_tril'}
     for case in cases:
         th = dev(case['theta'], gpu_device)
         if case['family'] == 'gmm_fullcov':
@@ -43,6 +43,11 @@ def test_golden_vectors(nat, ws, gpu_device):
             assert_logp_close(lp.cpu().numpy(), case['logp'])
             assert_grad_close(g.cpu().numpy(), case['grad'], term_scale=np.full_like(np.asarray(case['grad']),
                                                                                       3.0 * len(case['Y'])))
+            continue
+        if case['family'] == 'mvn_tril':
+            lp, g = nat.mvn_tril_logp_grad(dev(case['Y'], gpu_device), th, nat.MVN_CHOL_PRECISION_SOLVE, ws)
+            assert_logp_close(lp.cpu().numpy(), case['logp'])
+            assert_grad_close(g.cpu().numpy(), case['grad'])
             continue
         y = dev(case['y'], gpu_device)
         if case['family'] == 'normal_iid':

@@ -360,3 +360,103 @@ def test_posterior_predictive_sampling():
     assert s['y'].shape == (3000, 5)
     near = (s['y'][..., None] - torch.tensor([-10., 0., 10.])).abs().min(-1).values
     assert float((near < 3).float().mean()) > 0.97
+
+
+# ---- the multivariate Gaussian with a Wishart prior on the Cholesky factor of its precision
+# (exploratory_experiments/multivariate-gaussian-test.ipynb cell 15) ----
+def _mvn_wishart_model(dims=2, wishart_scale=None):
+    from bayes_vi_amd import linalg as tfl
+    priors = collections.OrderedDict(
+        loc=tfd.MultivariateNormalDiag(loc=[0.] * dims, scale_diag=[10.] * dims),
+        precision=tfd.WishartTriL(df=5, scale_tril=10.0 * torch.eye(dims) if wishart_scale is None else wishart_scale,
+                                  input_output_cholesky=True))
+
+    def likelihood(loc, precision):
+        return tfd.MultivariateNormalTriL(loc=loc, scale_tril=tfl.cholesky_solve(precision, tfl.eye(dims)))
+
+    bij = [tfb.Identity(), tfb.FillScaleTriL(diag_bijector=tfb.Softplus(), diag_shift=1e-3)]
+    return Model(priors=priors, likelihood=likelihood, constraining_bijectors=bij)
+
+
+def test_wishart_tril_against_scipy_and_oracle():
+    from scipy import stats
+    rng = np.random.default_rng(5)
+    for d, df in ((2, 5.0), (3, 4.5), (5, 9.0)):
+        S = np.tril(rng.normal(size=(d, d)) * 0.3) + np.eye(d) * 2.0
+        L = np.tril(rng.normal(size=(6, d, d)) * 0.5)
+        for i in range(d):
+            L[:, i, i] = rng.uniform(0.5, 2.0, 6)
+        dist = tfd.WishartTriL(df=df, scale_tril=torch.tensor(S), input_output_cholesky=True)
+        x = torch.tensor(L.reshape(6, -1))
+        lp, g = dist.log_prob_flat(x).numpy(), dist.score_flat(x).numpy()
+        ref = np.array([stats.wishart.logpdf(l @ l.T, df, S @ S.T) for l in L])
+        np.testing.assert_allclose(lp, ref, rtol=2e-6, atol=2e-5)            # hyper-parameters are held in float32
+        olp, og = cf.wishart_tril_prior(L.reshape(6, -1), df, S)
+        np.testing.assert_allclose(lp, olp, rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(g, og, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dist.log_prob(torch.tensor(L)).numpy(), lp)
+    # draws are Cholesky factors with E[L L^T] = df V
+    dist = tfd.WishartTriL(df=7.0, scale_tril=torch.tensor([[2.0, 0.0], [0.5, 1.0]]), input_output_cholesky=True)
+    gen = torch.Generator().manual_seed(1)
+    Ls = dist.sample((40000,), generator=gen)
+    assert Ls.shape == (40000, 2, 2) and bool((Ls[:, 0, 1] == 0).all()) and bool((torch.diagonal(Ls, dim1=-2, dim2=-1) > 0).all())
+    V = dist.scale_tril @ dist.scale_tril.T
+    np.testing.assert_allclose((Ls @ Ls.transpose(-1, -2)).mean(0).numpy(), 7.0 * V.numpy(), rtol=0.03, atol=0.1)
+    with pytest.raises(NotImplementedError):
+        tfd.WishartTriL(df=5, scale_tril=torch.eye(2))
+
+
+def test_recognise_mvn_with_cholesky_precision():
+    from bayes_vi_amd import linalg as tfl
+    from bayes_vi_amd import _native
+    from bayes_vi_amd.fused_target import Posterior
+    m = _mvn_wishart_model(2)
+    assert m.param_names == ['loc', 'precision']
+    assert m.block_sizes == [2, 4] and m.unconstrained_block_sizes == [2, 3]
+    assert m.flat_unconstrained_param_event_ndims == 5
+    assert m.constraining_bijectors[1].d == 2 and m.constraining_bijectors[1].diag_shift == 1e-3
+    desc = m.describe_likelihood()
+    assert desc == dict(family='mvn_tril', d=2, parameterisation='cholesky_solve_identity', index=[0, 1, 2, 3, 4, 5])
+    # scale_tril given directly, parameters in the other order
+    priors = collections.OrderedDict(s=tfd.WishartTriL(df=4, scale_tril=torch.eye(3), input_output_cholesky=True),
+                                     mu=tfd.MultivariateNormalDiag(loc=[0.] * 3, scale_diag=[1., 2., 3.]))
+    m2 = Model(priors=priors, likelihood=lambda s, mu: tfd.MultivariateNormalTriL(loc=mu, scale_tril=s))
+    d2 = m2.describe_likelihood()
+    assert d2['parameterisation'] == 'scale_tril' and d2['index'] == [9, 10, 11] + list(range(9))
+    assert isinstance(m2.constraining_bijectors[0], tfb.FillScaleTriL) and m2.constraining_bijectors[0].d == 3
+    with pytest.raises(sym.UnsupportedLikelihood):
+        Model(priors=priors, likelihood=lambda s, mu: tfd.MultivariateNormalTriL(
+            loc=mu, scale_tril=tfl.cholesky_solve(s, tfl.eye(2)))).describe_likelihood()
+    # the device-side description of priors and bijectors: Normal(0, 10) on loc, Wishart(5, 10 I) on the factor
+    class _Lik:
+        n_params = 6
+    post = Posterior(_Lik(), [(p, n) for p, n in zip(m.priors.values(), m.block_sizes)], m.constraining_bijectors)
+    blocks = post.device_blocks()
+    assert blocks is not None and len(blocks) == 2
+    assert (blocks[0].bijector, blocks[0].prior, blocks[0].a, blocks[0].b) == (_native.BIJ_IDENTITY, _native.PRIOR_NORMAL, 0.0, 10.0)
+    assert (blocks[1].bijector, blocks[1].prior, blocks[1].a, blocks[1].b, blocks[1].dim) == \
+        (_native.BIJ_FILL_SCALE_TRIL, _native.PRIOR_WISHART_TRIL, 5.0, 10.0, 2)
+    assert abs(blocks[1].shift - 1e-3) < 1e-9
+    # a Wishart scale that is not a multiple of the identity, or per-element prior widths: the torch path
+    m3 = _mvn_wishart_model(2, wishart_scale=torch.tensor([[10.0, 0.0], [1.0, 10.0]]))
+    post3 = Posterior(_Lik(), [(p, n) for p, n in zip(m3.priors.values(), m3.block_sizes)], m3.constraining_bijectors)
+    assert post3.device_blocks() is None
+    # concrete tensors: cholesky_solve is the inverse of P P^T, whatever sits above the diagonal of P
+    P = torch.tensor([[2.0, 7.0], [0.5, 1.5]])
+    Pl = torch.tril(P)
+    np.testing.assert_allclose(tfl.cholesky_solve(P, tfl.eye(2)).numpy(), torch.linalg.inv(Pl @ Pl.T).numpy(), rtol=1e-5)
+
+
+def test_mvn_wishart_priors_and_bijector_match_oracle():
+    m = _mvn_wishart_model(3)
+    rng = np.random.default_rng(3)
+    z = rng.normal(size=(4, m.flat_unconstrained_param_event_ndims))
+    spec = cf.mvn_chol_precision_model(np.zeros((1, 3)))
+    theta = m.blockwise_constraining_bijector.forward(torch.tensor(z)).numpy()
+    np.testing.assert_allclose(theta, spec.constrain(z), rtol=1e-12, atol=1e-12)
+    olp, og = spec.log_prior(theta)
+    parts = torch.split(torch.tensor(theta), m.block_sizes, dim=-1)
+    lp = sum(p.log_prob_flat(x) for p, x in zip(m.priors.values(), parts)).numpy()
+    g = torch.cat([p.score_flat(x) for p, x in zip(m.priors.values(), parts)], -1).numpy()
+    np.testing.assert_allclose(lp, olp, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(g, og, rtol=1e-5, atol=1e-6)
