@@ -26,6 +26,7 @@
 // operands swapped -- where the accumulator registers are, lane for lane, BOTH operands of
 // S2 += (rho z)^T z, and S0/S1 are register sums.
 #include <stdlib.h>
+#include <type_traits>
 #include "bvi_common.h"
 
 namespace {
@@ -36,7 +37,8 @@ constexpr int TR = 16;        // rows per tile
 
 __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, int D,
                                 const float* __restrict__ center, float* __restrict__ Ainv,
-                                float* __restrict__ bvec, float* __restrict__ blo, float* __restrict__ cst) {
+                                float* __restrict__ bvec, float* __restrict__ blo, float* __restrict__ cst,
+                                float* __restrict__ anorm) {
   // blo: optional low part of b (b = bvec + blo to ~2^-48): b is common to all rows of a component, so its
   // rounding error would add up coherently over the rows
   // center: optional per-column shift the streaming kernel applies to the data (b = A (mu - center))
@@ -72,6 +74,152 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
     for (int m = 0; m < D; ++m) ld += log((double)L[m * D + m]);
     cst[c * K + k] = (float)(log((double)th[k]) - log(wsum) - ld - 0.5 * D * BVI_LN2PI_D);
   }
+  if (!anorm) return;
+  // An upper bound of the spectral norm of A, for the far-component test of the streaming kernel (fullcov_bounds):
+  // |A|_2^2 = lambda_max(M), M = A^T A, and lambda_max(M)^8 = lambda_max(M^8) <= |M^8|_F, which is within
+  // DP^(1/16) = 1.24 of it.  Three squarings in float, each normalised by its largest entry (thread j owns column j).
+  __shared__ float Mq[2][DP][DP + 1];
+  __shared__ float red[DP];
+  auto block_max = [&](float v) {
+    __syncthreads();
+    red[j] = v;
+    __syncthreads();
+    float m = 0.f;
+    for (int i = 0; i < DP; ++i) m = fmaxf(m, red[i]);   // NaN-blind on purpose: the sum below carries a NaN through
+    return m;
+  };
+  float cmax = 0.f;
+  for (int i = 0; i < DP; ++i) {
+    float v = 0.f;
+    for (int m = 0; m < DP; ++m) v = fmaf((float)A[m][i], (float)A[m][j], v);
+    Mq[0][i][j] = v;
+    cmax = fmaxf(cmax, fabsf(v));
+  }
+  float scale[4];
+  scale[0] = block_max(cmax);
+  int cur = 0;
+  for (int sq = 0; sq < 3; ++sq) {
+    const float inv = scale[sq] > 0.f ? 1.f / scale[sq] : 0.f;
+    cmax = 0.f;
+    for (int i = 0; i < DP; ++i) {
+      float v = 0.f;
+      for (int m = 0; m < DP; ++m) v = fmaf(Mq[cur][i][m] * inv, Mq[cur][m][j] * inv, v);
+      Mq[cur ^ 1][i][j] = v;
+      cmax = fmaxf(cmax, fabsf(v));
+    }
+    scale[sq + 1] = block_max(cmax);
+    cur ^= 1;
+  }
+  float fro = 0.f;
+  const float inv = scale[3] > 0.f ? 1.f / scale[3] : 0.f;
+  for (int i = 0; i < DP; ++i) fro = fmaf(Mq[cur][i][j] * inv, Mq[cur][i][j] * inv, fro);
+  __syncthreads();
+  red[j] = fro;
+  __syncthreads();
+  if (j == 0) {
+    float f = 0.f;
+    for (int i = 0; i < DP; ++i) f += red[i];
+    // lambda(M) <= s0 sqrt(s1 sqrt(s2 sqrt(s3 |N3|_F)))
+    float lam = scale[3] * sqrtf(f);
+    lam = scale[2] * sqrtf(lam);
+    lam = scale[1] * sqrtf(lam);
+    lam = scale[0] * sqrtf(lam);
+    anorm[c * K + k] = sqrtf(lam) * 1.0001f;
+  }
+}
+
+// Centre (column means) and radius (largest distance of a row from the centre) of every 64-row tile, raw
+// coordinates: tstat[tile][0 .. DP-1] = centre, [DP] = radius.  One wave per tile, lane = row.
+__global__ __launch_bounds__(256) void fullcov_tilestats(const float* __restrict__ Y, int64_t n, int D, int64_t ntiles,
+                                                         float* __restrict__ tstat) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int64_t row = tile * 64 + lane;
+  const bool valid = row < n;
+  const int64_t left = n - tile * 64;
+  const float icnt = 1.f / (float)(left < 64 ? left : 64);
+  float y[DP];
+  if (D == DP && (((uintptr_t)Y & 15) == 0)) {
+#pragma unroll
+    for (int q = 0; q < DP / 4; ++q) {
+      f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+      if (valid) t4 = *reinterpret_cast<const f32x4*>(Y + row * DP + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[4 * q + e] = t4[e];
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) y[d] = (valid && d < D) ? Y[row * D + d] : 0.f;
+  }
+  float dist2 = 0.f;
+  float* out = tstat + tile * (DP + 1);
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    float sm = y[d];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
+    const float m = sm * icnt;
+    if (lane == d) out[d] = m;
+    const float e = valid ? y[d] - m : 0.f;
+    dist2 = fmaf(e, e, dist2);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(dist2, off, 64);
+    dist2 = (o > dist2 || o != o) ? o : dist2;           // NaN wins: such a tile keeps every component
+  }
+  if (lane == 0) out[DP] = sqrtf(dist2);
+}
+
+// Which components a tile can leave out.  For a row y of the tile and u_k(y) = A_k (y - mu_k):
+//   | |u_k(y)| - |u_k(m)| | <= |A_k|_2 |y - m| <= anorm_k r      (m, r: the tile's centre and radius)
+// so a_k(y) = cst_k - |u_k(y)|^2 / 2 lies between cst_k - hi_k^2 / 2 and cst_k - lo_k^2 / 2 with
+// hi / lo = |u_k(m)| +- anorm_k r.  A component whose upper bound is more than 32 below the largest lower bound has
+// responsibilities below e^-32 = 2^-46 for every row of the tile: bit k of tmask[chain][tile] is cleared and the
+// streaming kernel does not evaluate it there (its terms are below the 2^-40 the raw-sums phase keeps anyway).
+// Anything non-finite keeps the bit set.  One thread per tile; A_k, b_k come through the scalar cache (read-only,
+// the same address in every lane).
+__global__ __launch_bounds__(256) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K,
+                                                      const float* __restrict__ Ainv, const float* __restrict__ bvec,
+                                                      const float* __restrict__ cst, const float* __restrict__ anorm,
+                                                      const float* __restrict__ center, int C,
+                                                      unsigned short* __restrict__ tmask) {
+  const int c = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float aub[16][256];
+  if (t >= ntiles) return;
+  const float* ts = tstat + t * (DP + 1);
+  float dm[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) dm[d] = ts[d] - center[d];
+  const float r = ts[DP];
+  float best = -INFINITY;
+  bool odd = false;                      // something is not finite: keep everything
+  for (int k = 0; k < K; ++k) {
+    const float* A = Ainv + ((int64_t)c * K + k) * DP * DP;
+    const float* b = bvec + ((int64_t)c * K + k) * DP;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+      float sacc = -b[i];
+#pragma unroll
+      for (int j = 0; j <= i; ++j) sacc = fmaf(A[i * DP + j], dm[j], sacc);
+      d2 = fmaf(sacc, sacc, d2);
+    }
+    const float dk = sqrtf(d2), slack = anorm[c * K + k] * r * 1.001f + 1e-3f;
+    const float lo = fmaxf(dk - slack, 0.f), hi = dk + slack;
+    const float ck = cst[c * K + k];
+    const float ub = ck - 0.5f * lo * lo, lb = ck - 0.5f * hi * hi;
+    aub[k][threadIdx.x] = ub;
+    if (lb > best) best = lb;
+    if (!(fabsf(ub) < INFINITY) || !(fabsf(lb) < INFINITY)) odd = odd || (ck > -INFINITY);
+  }
+  const float thresh = best - 32.f - 1e-4f * fabsf(best);
+  unsigned mask = 0;
+  for (int k = 0; k < K; ++k)
+    if (odd || !(aub[k][threadIdx.x] < thresh)) mask |= 1u << k;
+  tmask[(int64_t)c * ntiles + t] = (unsigned short)mask;
 }
 
 // The level a typical row's log-density sits at, from the components' constants as the kernels hold them (floats):
@@ -420,7 +568,8 @@ template <int KQ, bool GRAD>  // components per wave (K <= FW * KQ)
 __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD ? 2 : 4))) void fullcov_f16_kernel(
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
-    const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials) {
+    const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials,
+    const unsigned short* __restrict__ tmask) {
   // LDS: two f16 images of the tile (hi, lo), 64-B rows with the 16-B chunks XOR-swizzled by row so that the
   // A-operand ds_read_b128 (16 rows x two neighbouring chunks per lane group) is conflict-free; double buffered
   __shared__ __attribute__((aligned(16))) unsigned char ybuf[2][2][FT * 64];
@@ -533,14 +682,26 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
 
   const int64_t ntiles = (n + FT - 1) / FT;
   int64_t tile = blockIdx.x;
+  // bit k of a tile's mask clear: component k is out of reach of every row of the tile (fullcov_bounds)
+  const unsigned short* tm = tmask ? tmask + (int64_t)c * ntiles : nullptr;
+  unsigned mask_cur = 0xFFFFu, mask_nxt = 0xFFFFu;
   if (tile < ntiles) {
     gload(tile);
     lstore(0);
+    if (tm) mask_cur = tm[tile];
   }
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    if (tile + gridDim.x < ntiles) gload(tile + gridDim.x);
+    if (tile + gridDim.x < ntiles) {
+      gload(tile + gridDim.x);
+      if (tm) mask_nxt = tm[tile + gridDim.x];
+    }
+    const unsigned tile_mask = __builtin_amdgcn_readfirstlane(mask_cur);
+    mask_cur = mask_nxt;
+    bool act[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) act[q] = wave + FW * q < K && ((tile_mask >> (wave + FW * q)) & 1u) != 0;
     const unsigned char* yh = ybuf[buf][0];
     const unsigned char* yl = ybuf[buf][1];
     // ---- GEMM1: u = A (y - mu) for the wave's components, rows 4 g + i of each 16-row tile in registers ----
@@ -550,8 +711,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     // + one chunk of vector work per slot with a scheduling barrier after each, because left to itself the
     // compiler emits the eight MFMAs back to back and the 40 vector instructions after them.
     f32x4 u[GRAD ? KQ : 1][4][2];
-    {
-      constexpr int NG = 4 * KQ;
+    // the (row tile, component) groups of the components Q0 .. Q0 + NQ - 1 of this wave
+    auto gemm1 = [&](auto q0_c, auto nq_c) {
+      constexpr int Q0 = decltype(q0_c)::value, NQ = decltype(nq_c)::value;
+      constexpr int NG = 4 * NQ;
       f16x8 fh[2], fl[2];                    // A operands of the row tile being multiplied / the next one
       f32x4 zc[2], zn[2];
       auto load_tile = [&](int rt, int slot) {
@@ -571,11 +734,11 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       Row16Sum4 rs;
       load_tile(0, 0);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) mfma_step(0, 0, m, zc);
+      for (int m = 0; m < 8; ++m) mfma_step(Q0, 0, m, zc);
 #pragma unroll
       for (int j = 0; j < NG; ++j) {
-        const int rt = j / KQ, q = j % KQ;
-        const int jn = j + 1, rtn = jn / KQ, qn = jn % KQ;
+        const int rt = j / NQ, q = Q0 + j % NQ;
+        const int jn = j + 1, rtn = jn / NQ, qn = Q0 + jn % NQ;
         // The two waves of a SIMD (w and w + FW / 2) run the same stream between the same barriers; left alone the
         // older one wins every issue slot, reaches the barrier early and waits while the other finishes on its
         // own.  Issue priorities by phase, found by measurement (13.6 ms without any -> 12.9 ms; the eighteen other
@@ -586,7 +749,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
           if (j == 0 || !lead_wave) __builtin_amdgcn_s_setprio(1);
           else __builtin_amdgcn_s_setprio(0);
         }
-        if (jn < NG && qn == 0) load_tile(rtn, rtn & 1);
+        if (jn < NG && qn == Q0) load_tile(rtn, rtn & 1);
         // Value only: the row sums of group j - 1 ride in the odd slots of group j (no padding; measured faster
         // at four waves per SIMD).  With the gradient (two waves per SIMD) the padded steps in the group's own
         // slots measured faster.
@@ -612,7 +775,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
           }
           // |u|^2 of row 16 rt + 4 g + b is now in the lanes of bank b
           if (j > 0 && (ln & 3) == 0)
-            al[wave + FW * ((j - 1) % KQ)][16 * ((j - 1) / KQ) + 4 * g + (ln >> 2)] = cq[(j - 1) % KQ] - 0.5f * rs.d0;
+            al[wave + FW * (Q0 + (j - 1) % NQ)][16 * ((j - 1) / NQ) + 4 * g + (ln >> 2)] = cq[Q0 + (j - 1) % NQ] - 0.5f * rs.d0;
         } else {
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
@@ -638,9 +801,24 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
 #pragma unroll
         for (int k = 0; k < 4; ++k) rs.template step<true>(k, nrm[(NG - 1) & 1]);
         if ((ln & 3) == 0)
-          al[wave + FW * ((NG - 1) % KQ)][16 * ((NG - 1) / KQ) + 4 * g + (ln >> 2)] = cq[(NG - 1) % KQ] - 0.5f * rs.d0;
+          al[wave + FW * (Q0 + (NG - 1) % NQ)][16 * ((NG - 1) / NQ) + 4 * g + (ln >> 2)] = cq[Q0 + (NG - 1) % NQ] - 0.5f * rs.d0;
       }
+    };
+    // A component the tile's mask rules out is not evaluated: its log-densities enter the log-sum-exp as -inf (so
+    // its responsibilities, flags and raw sums are exactly zero), the matrix and vector work of its groups is skipped
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if constexpr (KQ == 1) {
+      if (act[0]) gemm1(I0{}, I1{});
+    } else {
+      if (act[0] && act[1]) gemm1(I0{}, I2{});
+      else if (act[0]) gemm1(I0{}, I1{});
+      else if (act[1]) gemm1(I1{}, I1{});
     }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+      if (!act[q] && wave + FW * q < K) al[wave + FW * q][lane] = -INFINITY;
     __syncthreads();
     {
       // log-sum-exp over the components and sqrt(rho_ik) = exp((a_ik - lse) / 2), shared out over the workgroup: wave w
@@ -874,11 +1052,17 @@ constexpr int kStatBlocks = 256;
 // floats of workspace in front of everything else: column statistics of Y (doubles first: 8-B aligned)
 constexpr size_t kStatFloats = 2 * (size_t)kStatBlocks * DP + 2 * (size_t)kStatBlocks * DP + 2 * DP;
 
+// floats for the far-component test: per-tile centre + radius, |A_k|_2 bounds, the tiles' component masks (16 bits each)
+size_t fullcov_tile_floats(int64_t n, int c, int k) {
+  const size_t ntiles = (size_t)((n + FT - 1) / FT);
+  return ntiles * (DP + 1) + (size_t)c * k + ((size_t)c * ntiles + 1) / 2 + 2;
+}
+
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
   (void)d;
   const size_t prep = (size_t)c * k * (DP * DP + 2 * DP + 1);
   const size_t part = (size_t)fullcov_blocks(n, c) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
-  return (kStatFloats + prep + part) * sizeof(float);
+  return (kStatFloats + prep + part + fullcov_tile_floats(n, c, k)) * sizeof(float);
 }
 
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
@@ -895,6 +1079,10 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   float* blo = bvec + (size_t)c * k * DP;
   float* cst = blo + (size_t)c * k * DP;
   float* partials = cst + (size_t)c * k;
+  const int64_t ntiles = (n + FT - 1) / FT;
+  float* tstat = partials + (size_t)fullcov_blocks(n, c) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
+  float* anorm = tstat + (size_t)ntiles * (DP + 1);
+  unsigned short* tmask = reinterpret_cast<unsigned short*>(anorm + (size_t)c * k);
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
   static const bool use_f32 = getenv("BVI_FULLCOV_F32") && atoi(getenv("BVI_FULLCOV_F32")) != 0;
@@ -902,7 +1090,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   dim3 grid(nb, c);
   if (use_f32) {
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)nullptr, Ainv,
-                       bvec, (float*)nullptr, cst);
+                       bvec, (float*)nullptr, cst, (float*)nullptr);
     BVI_HIP_CHECK_LAUNCH();
     const int kq = bvi_ceil_div(k, 4);
     const size_t lds = ((size_t)k * DP * LS + (size_t)k * DP + TR * LS + 4 * kq * TR + TR + 4 * kq) * sizeof(float);
@@ -924,13 +1112,24 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     hipLaunchKernelGGL(fullcov_colstats, dim3(kStatBlocks), dim3(256), 0, s, Y, n, d, psum, pmin, pmax);
     hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(256), 0, s, (const double*)psum, (const float*)pmin,
                        (const float*)pmax, kStatBlocks, n, d, center, cscale);
+    // one component: nothing to leave out
+    static const bool no_prune = getenv("BVI_FULLCOV_NO_PRUNE") && atoi(getenv("BVI_FULLCOV_NO_PRUNE")) != 0;
+    const bool prune = k > 1 && ntiles > 0 && !no_prune;
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
-                       bvec, blo, cst);
+                       bvec, blo, cst, prune ? anorm : (float*)nullptr);
     BVI_HIP_CHECK_LAUNCH();
+    if (prune) {
+      hipLaunchKernelGGL(fullcov_tilestats, dim3((unsigned)bvi_ceil_div(ntiles, 4)), dim3(256), 0, s, Y, n, d, ntiles, tstat);
+      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ntiles, 256), c), dim3(256), 0, s, (const float*)tstat,
+                         ntiles, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
+                         (const float*)center, c, tmask);
+      BVI_HIP_CHECK_LAUNCH();
+    }
+    const unsigned short* tmask_arg = prune ? tmask : nullptr;
 #define BVI_FC16(KQ, GRAD)                                                                                          \
   hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,           \
                      (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
-                     c, partials)
+                     c, partials, tmask_arg)
     if (k <= FW) {
       if (grad) BVI_FC16(1, true); else BVI_FC16(1, false);
     } else {
