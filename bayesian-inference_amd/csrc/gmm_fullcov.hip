@@ -563,13 +563,71 @@ __global__ __launch_bounds__(256) void fullcov_colstats_final(const double* __re
   cscale[col] = sc;
 }
 
+
+// Replication of the components over the waves of fullcov_single_kernel: with K <= 4 components each is given to
+// R = 8, 4 or 2 waves (every wave then has work), otherwise to one.
+__host__ __device__ __forceinline__ int fullcov_replicas(int K) { return K <= 1 ? 8 : K <= 2 ? 4 : K <= 4 ? 2 : 1; }
+
+// Sorts the tiles of every (chain, row block) into 2 FW + 1 lists, ascending inside each: list w + FW q (w < FW,
+// q < 2) = the tiles that ONE component reaches, namely component (w % K8) + FW q, and that wave w of
+// fullcov_single_kernel takes (with replicated components the replicas take turns); list 2 FW = the tiles several
+// components reach (fullcov_f16_kernel).  tlist[(chain, block)][cap] holds the lists back to back,
+// toff[(chain, block)][kListOffs] their starts and the end.  tmask == nullptr: every tile is reached by all K
+// components.  One wave per (chain, block), 64 tiles per step, positions from ballots.
+constexpr int kLists = 2 * FW + 1, kListOffs = kLists + 1;
+__global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __restrict__ tmask, int64_t ntiles, int K,
+                                                        int cap, int* __restrict__ tlist, int* __restrict__ toff) {
+  const int c = blockIdx.y, b = blockIdx.x, nb = gridDim.x, lane = threadIdx.x;
+  const int R = fullcov_replicas(K), K8 = FW / R;
+  const unsigned kmask = (1u << K) - 1u;
+  int* seg = tlist + ((int64_t)c * nb + b) * cap;
+  int* so = toff + ((int64_t)c * nb + b) * kListOffs;
+  const int cnt_tiles = b < ntiles ? (int)((ntiles - b + nb - 1) / nb) : 0;
+  auto classify = [&](int i, int& entry) -> int {     // i-th tile of this block; returns its list, -1 past the end
+    if (i >= cnt_tiles) return -1;
+    const int64_t t = b + (int64_t)i * nb;
+    const unsigned m = tmask ? (tmask[(int64_t)c * ntiles + t] & kmask) : kmask;
+    entry = (int)t;
+    if (__builtin_popcount(m) != 1) return 2 * FW;
+    const int k = __builtin_ctz(m);
+    return (k % FW) % K8 + K8 * (i % R) + (k >= FW ? FW : 0);
+  };
+  int count[kLists];
+#pragma unroll
+  for (int j = 0; j < kLists; ++j) count[j] = 0;
+  for (int i0 = 0; i0 < cnt_tiles; i0 += 64) {
+    int e;
+    const int cl = classify(i0 + lane, e);
+#pragma unroll
+    for (int j = 0; j < kLists; ++j) count[j] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cl == j));
+  }
+  int start[kLists], run = 0;
+#pragma unroll
+  for (int j = 0; j < kLists; ++j) { start[j] = run; run += count[j]; }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < kLists; ++j) so[j] = start[j];
+    so[kLists] = run;
+  }
+  for (int i0 = 0; i0 < cnt_tiles; i0 += 64) {
+    int e = 0;
+    const int cl = classify(i0 + lane, e);
+#pragma unroll
+    for (int j = 0; j < kLists; ++j) {
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(cl == j);
+      if (cl == j) seg[start[j] + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = e;
+      start[j] += __builtin_popcountll(bal);
+    }
+  }
+}
+
 // GRAD = false (value only, what random-walk Metropolis asks for): no responsibilities, no raw sums
 template <int KQ, bool GRAD>  // components per wave (K <= FW * KQ)
 __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD ? 2 : 4))) void fullcov_f16_kernel(
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
     const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials,
-    const unsigned short* __restrict__ tmask) {
+    const unsigned short* __restrict__ tmask, const int* __restrict__ tlist, const int* __restrict__ toff, int cap) {
   // LDS: two f16 images of the tile (hi, lo), 64-B rows with the 16-B chunks XOR-swizzled by row so that the
   // A-operand ds_read_b128 (16 rows x two neighbouring chunks per lane group) is conflict-free; double buffered
   __shared__ __attribute__((aligned(16))) unsigned char ybuf[2][2][FT * 64];
@@ -681,21 +739,30 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   };
 
   const int64_t ntiles = (n + FT - 1) / FT;
-  int64_t tile = blockIdx.x;
+  // This workgroup's tiles: those of its row block that several components reach (fullcov_tilelists, the last list); the
+  // tiles only one component reaches go to fullcov_single_kernel.
+  const int* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
+  const int* so = toff + ((int64_t)c * gridDim.x + blockIdx.x) * kListOffs;
+  const int li1 = so[kLists];
+  int li = so[kLists - 1];
   // bit k of a tile's mask clear: component k is out of reach of every row of the tile (fullcov_bounds)
   const unsigned short* tm = tmask ? tmask + (int64_t)c * ntiles : nullptr;
   unsigned mask_cur = 0xFFFFu, mask_nxt = 0xFFFFu;
-  if (tile < ntiles) {
+  int64_t tile = 0, tile_nxt = 0;
+  if (li < li1) {
+    tile = seg[li];
     gload(tile);
     lstore(0);
     if (tm) mask_cur = tm[tile];
   }
   __syncthreads();
   int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    if (tile + gridDim.x < ntiles) {
-      gload(tile + gridDim.x);
-      if (tm) mask_nxt = tm[tile + gridDim.x];
+  for (; li < li1; ++li, tile = tile_nxt) {
+    const bool more = li + 1 < li1;
+    if (more) {
+      tile_nxt = seg[li + 1];
+      gload(tile_nxt);
+      if (tm) mask_nxt = tm[tile_nxt];
     }
     const unsigned tile_mask = __builtin_amdgcn_readfirstlane(mask_cur);
     mask_cur = mask_nxt;
@@ -917,7 +984,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
         }
       }
     }
-    if (tile + gridDim.x < ntiles) lstore(buf ^ 1);
+    if (more) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
@@ -972,6 +1039,257 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     float s = 0.f;
     for (int i = 0; i < FT; ++i) s += lpw[i];
     out[(int64_t)K * Q] = s;
+  }
+}
+
+
+// The tiles only ONE component reaches.  There every responsibility is 1 and a row's log-density is that component's:
+// no log-sum-exp, nothing to exchange between waves, no LDS staging and no barrier.  Every wave works through its own
+// lists of tiles (fullcov_tilelists) by itself, one component after the other: it loads the rows of a tile straight
+// into the A-operand layout of the residual product (lane = row 16 rt + ln, dims 8 g .. 8 g + 7; the next tile's rows
+// are in flight meanwhile), splits them into f16 pieces in registers, and runs the same two products as
+// fullcov_f16_kernel: residuals (four f16 products), |u|^2 by DPP row sums, then S0 += 1, S1 += u, S2 += u u^T.  Rows
+// past the end or beyond the f16 range of u (absurd parameters) get weight 0 through a per-wave LDS line.
+// Wave w owns components (w % K8) and (w % K8) + FW, K8 = FW / R; with R > 1 (K <= 4) wave w is replica w / K8 and
+// writes the partial sums of block R * blockIdx.x + replica.
+template <bool GRAD>
+__global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD ? 2 : 4))) void fullcov_single_kernel(
+    const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
+    const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
+    const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials,
+    const int* __restrict__ tlist, const int* __restrict__ toff, int cap) {
+  __shared__ float sqw[FW][FT];
+  __shared__ double lpw[FW];
+  // column centres and scales: read from LDS where they are used (registers are short)
+  __shared__ __attribute__((aligned(16))) float cms[2][DP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, g = lane >> 4;
+  const int c = blockIdx.y;
+  const int R = fullcov_replicas(K), K8 = FW / R, kbase = wave % K8, rep = wave / K8;
+  if (tid < DP) { cms[0][tid] = center[tid]; cms[1][tid] = cscale[tid]; }
+  __syncthreads();
+
+  constexpr int Q = 1 + DP + DP * DP;
+  float* out = partials + (((int64_t)blockIdx.x * R + rep) * C + c) * ((int64_t)K * Q + 1);
+  double logp_acc = 0.0;
+  const float row_level = fullcov_row_level(cst + (int64_t)c * K, K, D);
+  const bool vec_ok = D == DP && (((uintptr_t)Y & 15) == 0);
+  f32x4 raw[4][2];
+  auto gload = [&](int64_t tile) {          // rows 16 rt + ln of the tile, dims 8 g .. 8 g + 7; past the end: the centre
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int64_t gr = tile * FT + 16 * rt + ln;
+      if (vec_ok && gr < n) {
+        raw[rt][0] = *reinterpret_cast<const f32x4*>(Y + gr * DP + 8 * g);
+        raw[rt][1] = *reinterpret_cast<const f32x4*>(Y + gr * DP + 8 * g + 4);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool in = gr < n && 8 * g + e < D;
+          const float y = Y[in ? gr * D + 8 * g + e : 0];      // (a tile exists, so Y[0] does)
+          raw[rt][e >> 2][e & 3] = in ? y : cms[0][8 * g + e];
+        }
+      }
+    }
+  };
+  const int* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
+  const int* so = toff + ((int64_t)c * gridDim.x + blockIdx.x) * kListOffs;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  for (int q = 0; q < 2; ++q) {
+    const int k = kbase + FW * q;
+    if (k >= K) break;
+    // A''_k as B operand of the residual product, three f16 pieces, as in fullcov_f16_kernel
+    f16x8 a1[2], a2[2], a3[2];
+    float inv_t, zb[2], bl[2];
+    {
+      const float* Ak = Ainv + ((int64_t)c * K + k) * DP * DP;
+      float v[2][8], amax = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int d = 8 * g + j;
+          const float sc = cms[1][d];
+          v[nt][j] = sc > 0.f ? Ak[(16 * nt + ln) * DP + d] / sc : 0.f;
+          amax = fmaxf(amax, fabsf(v[nt][j]));
+        }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+      const float t = fc_pow2_scale(amax);
+      inv_t = 1.f / t;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = v[nt][j] * t;
+          const _Float16 hi = fabsf(x) < 1024.f ? (_Float16)rintf(x) : (_Float16)x;
+          const _Float16 lo = (_Float16)(x - (float)hi);
+          a1[nt][j] = hi;
+          a2[nt][j] = lo;
+          a3[nt][j] = (_Float16)((x - (float)hi) - (float)lo);
+        }
+        zb[nt] = -t * bvec[((int64_t)c * K + k) * DP + 16 * nt + ln];
+        bl[nt] = blo[((int64_t)c * K + k) * DP + 16 * nt + ln];
+      }
+    }
+    const float cq = cst[c * K + k];
+    f32x4 S2[2][2];
+    float S1[2] = {0.f, 0.f}, S0 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) S2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int li = so[wave + FW * q];
+    const int li1 = so[wave + FW * q + 1];
+    int64_t tile = 0;
+    if (li < li1) {
+      tile = seg[li];
+      gload(tile);
+    }
+    for (; li < li1; ++li) {
+      // the tile's rows as f16 pieces (A operands); the staging registers are then free for the next tile's rows
+      f16x8 fh[4], fl[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 cm = *reinterpret_cast<const f32x4*>(&cms[0][8 * g + 4 * h]);
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(&cms[1][8 * g + 4 * h]);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float q0 = (raw[rt][h][e] - cm[e]) * cs[e];
+            const float q1 = (raw[rt][h][e + 1] - cm[e + 1]) * cs[e + 1];
+            fc_split_pair(q0, q1, hw[2 * h + (e >> 1)], lw[2 * h + (e >> 1)]);
+          }
+        }
+        fh[rt] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+        fl[rt] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+      }
+      const int64_t tile_cur = tile;
+      if (li + 1 < li1) {
+        tile = seg[li + 1];
+        gload(tile);
+      }
+      f32x4 u[GRAD ? 4 : 1][2];
+      f32x4 zc[2], zn[2];
+      float arow[4];                         // log-density of row 16 rt + 4 g + (ln >> 2)
+      // MFMA m (0..7) of a row tile: chain nt = m & 1, product m >> 1 of (yh a1, yl a1, yh a2, yh a3), on top of -t b_hi
+      auto mfma_step = [&](int rt, int m, f32x4 (&z)[2]) {
+        const int nt = m & 1, pr = m >> 1;
+        const f16x8 av = pr <= 1 ? a1[nt] : (pr == 2 ? a2[nt] : a3[nt]);
+        const f16x8 yv = pr == 1 ? fl[rt] : fh[rt];
+        const f32x4 c0 = {zb[nt], zb[nt], zb[nt], zb[nt]};
+        z[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yv, av, pr == 0 ? c0 : z[nt], 0, 0, 0);
+      };
+      float nrm[4];
+      Row16Sum4 rs;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) mfma_step(0, m, zc);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          if (rt + 1 < 4) mfma_step(rt + 1, m, zn);
+          if (m < 4) {
+            const float u0 = fmaf(zc[0][m], inv_t, -bl[0]);
+            const float u1 = fmaf(zc[1][m], inv_t, -bl[1]);
+            if constexpr (GRAD) {
+              u[GRAD ? rt : 0][0][m] = u0;
+              u[GRAD ? rt : 0][1][m] = u1;
+            }
+            nrm[m] = fmaf(u1, u1, u0 * u0);
+          } else {
+            rs.template step<true>(m - 4, nrm);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        arow[rt] = cq - 0.5f * rs.d0;
+        if (rt + 1 < 4) { zc[0] = zn[0]; zc[1] = zn[1]; }
+      }
+      // log-densities (one of the four lanes that hold a row's value adds it) and the rows' weights
+      bool ok = true;
+      float sv[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const bool valid = tile_cur * FT + 16 * rt + 4 * g + (ln >> 2) < n;
+        const float a = arow[rt];
+        if (valid && (ln & 3) == 0) logp_acc += (double)(a - row_level);
+        sv[rt] = valid ? (a > cq - 1.5e9f ? 1.f : (a != a ? a : 0.f)) : 0.f;
+        ok = ok && sv[rt] == 1.f;
+        if (GRAD && (ln & 3) == 0) S0 = fmaf(sv[rt], sv[rt], S0);
+      }
+      if constexpr (GRAD) {
+        const bool all_ok = __builtin_amdgcn_ballot_w64(ok) == ~0ull;
+        if (!all_ok) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+            if ((ln & 3) == 0) sqw[wave][16 * rt + 4 * g + (ln >> 2)] = sv[rt];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {        // 32-row pairs: k index j <-> row 32 m + 16 (j >> 2) + 4 g + (j & 3)
+          float sr[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sr[j] = all_ok ? 1.f : sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3)];
+          f16x8 wh[2], wl[2];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const float w0 = sr[j] * u[2 * m + (j >> 2)][nt][j & 3];
+              const float w1 = sr[j + 1] * u[2 * m + (j >> 2)][nt][(j & 3) + 1];
+              S1[nt] = fmaf(sr[j], w0, S1[nt]);
+              S1[nt] = fmaf(sr[j + 1], w1, S1[nt]);
+              fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
+            }
+            wh[nt] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
+            wl[nt] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = a; b < 2; ++b) {
+              S2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], wh[b], S2[a][b], 0, 0, 0);
+              S2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[a], wh[b], S2[a][b], 0, 0, 0);
+              S2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], wl[b], S2[a][b], 0, 0, 0);
+            }
+        }
+      }
+    }
+
+    // ---- partials of (row block, replica, chain), component k: the layout of fullcov_f16_kernel ----
+    if constexpr (GRAD) {
+      float s0 = S0;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) s0 += __shfl_xor(s0, off, 64);
+      if (lane == 0) out[(int64_t)k * Q] = s0;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float s1 = S1[nt];
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (g == 0) out[(int64_t)k * Q + 1 + 16 * nt + ln] = s1;
+#pragma unroll
+        for (int b = nt; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            out[(int64_t)k * Q + 1 + DP + (16 * nt + 4 * g + i) * DP + 16 * b + ln] = S2[nt][b][i];
+            if (b != nt) out[(int64_t)k * Q + 1 + DP + (16 * b + ln) * DP + 16 * nt + 4 * g + i] = S2[nt][b][i];
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) logp_acc += __shfl_xor(logp_acc, off, 64);
+  if (lane == 0) lpw[wave] = logp_acc;
+  __syncthreads();
+  if (lane == 0 && kbase == 0) {
+    double t = 0.0;
+    for (int w = 0; w < K8; ++w) t += lpw[rep * K8 + w];
+    out[(int64_t)K * Q] = (float)t;
   }
 }
 
@@ -1052,16 +1370,27 @@ constexpr int kStatBlocks = 256;
 // floats of workspace in front of everything else: column statistics of Y (doubles first: 8-B aligned)
 constexpr size_t kStatFloats = 2 * (size_t)kStatBlocks * DP + 2 * (size_t)kStatBlocks * DP + 2 * DP;
 
-// floats for the far-component test: per-tile centre + radius, |A_k|_2 bounds, the tiles' component masks (16 bits each)
+// tiles per row block, at most
+int fullcov_list_cap(int64_t n, int nb) {
+  const int64_t ntiles = (n + FT - 1) / FT;
+  return (int)((ntiles + nb - 1) / nb) + 1;
+}
+
+// floats for the far-component test and the tile lists: per-tile centre + radius, |A_k|_2 bounds, the tiles'
+// component masks (16 bits each), the lists (one int per tile and (chain, block) slot) and their offsets
 size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t ntiles = (size_t)((n + FT - 1) / FT);
-  return ntiles * (DP + 1) + (size_t)c * k + ((size_t)c * ntiles + 1) / 2 + 2;
+  const size_t nb = (size_t)fullcov_blocks(n, c);
+  return ntiles * (DP + 1) + (size_t)c * k + ((size_t)c * ntiles + 1) / 2 + 2 +
+         (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
 }
 
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
   (void)d;
   const size_t prep = (size_t)c * k * (DP * DP + 2 * DP + 1);
-  const size_t part = (size_t)fullcov_blocks(n, c) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
+  // partial sums: one set per row block from the kernel of the tiles several components reach, R sets per row
+  // block from the kernel of the tiles one component reaches
+  const size_t part = (size_t)fullcov_blocks(n, c) * (1 + fullcov_replicas(k)) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
   return (kStatFloats + prep + part + fullcov_tile_floats(n, c, k)) * sizeof(float);
 }
 
@@ -1080,13 +1409,18 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   float* cst = blo + (size_t)c * k * DP;
   float* partials = cst + (size_t)c * k;
   const int64_t ntiles = (n + FT - 1) / FT;
-  float* tstat = partials + (size_t)fullcov_blocks(n, c) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
+  const int nblk = fullcov_blocks(n, c), reps = fullcov_replicas(k), cap = fullcov_list_cap(n, nblk);
+  const size_t pstride = (size_t)c * ((size_t)k * (1 + DP + DP * DP) + 1);
+  float* tstat = partials + (size_t)nblk * (1 + reps) * pstride;
   float* anorm = tstat + (size_t)ntiles * (DP + 1);
   unsigned short* tmask = reinterpret_cast<unsigned short*>(anorm + (size_t)c * k);
+  int* tlist = reinterpret_cast<int*>(anorm + (size_t)c * k + ((size_t)c * ntiles + 1) / 2 + 2);
+  int* toff = tlist + (size_t)c * nblk * cap;
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
   static const bool use_f32 = getenv("BVI_FULLCOV_F32") && atoi(getenv("BVI_FULLCOV_F32")) != 0;
   const int nb = fullcov_blocks(n, c);
+  int nb_total = nb;
   dim3 grid(nb, c);
   if (use_f32) {
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)nullptr, Ainv,
@@ -1126,19 +1460,28 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
       BVI_HIP_CHECK_LAUNCH();
     }
     const unsigned short* tmask_arg = prune ? tmask : nullptr;
+    // one component: every tile is a single-component tile; no pruning otherwise: none is
+    const bool lists_from_masks = prune || k == 1;
+    hipLaunchKernelGGL(fullcov_tilelists, dim3(nblk, c), dim3(64), 0, s, lists_from_masks ? tmask_arg : (const unsigned short*)nullptr,
+                       ntiles, lists_from_masks ? k : 16, cap, tlist, toff);
+    BVI_HIP_CHECK_LAUNCH();
 #define BVI_FC16(KQ, GRAD)                                                                                          \
   hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,           \
                      (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
-                     c, partials, tmask_arg)
+                     c, partials, tmask_arg, (const int*)tlist, (const int*)toff, cap);                                     \
+  hipLaunchKernelGGL((fullcov_single_kernel<GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,            \
+                     (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
+                     c, partials + (size_t)nblk * pstride, (const int*)tlist, (const int*)toff, cap)
     if (k <= FW) {
-      if (grad) BVI_FC16(1, true); else BVI_FC16(1, false);
+      if (grad) { BVI_FC16(1, true); } else { BVI_FC16(1, false); }
     } else {
-      if (grad) BVI_FC16(2, true); else BVI_FC16(2, false);
+      if (grad) { BVI_FC16(2, true); } else { BVI_FC16(2, false); }
     }
 #undef BVI_FC16
+    nb_total = nblk * (1 + reps);
   }
   BVI_HIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(8 * DP), 0, s, (const float*)partials, nb, n, d, k, theta,
+  hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(8 * DP), 0, s, (const float*)partials, nb_total, n, d, k, theta,
                      (const float*)Ainv, use_f32 ? (const float*)nullptr : (const float*)cst, c, logp, grad, logp_ref);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
