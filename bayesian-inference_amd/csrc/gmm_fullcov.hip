@@ -38,7 +38,7 @@ constexpr int TR = 16;        // rows per tile
 __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, int D,
                                 const float* __restrict__ center, float* __restrict__ Ainv,
                                 float* __restrict__ bvec, float* __restrict__ blo, float* __restrict__ cst,
-                                float* __restrict__ anorm) {
+                                float* __restrict__ anorm, float* __restrict__ mudist) {
   // blo: optional low part of b (b = bvec + blo to ~2^-48): b is common to all rows of a component, so its
   // rounding error would add up coherently over the rows
   // center: optional per-column shift the streaming kernel applies to the data (b = A (mu - center))
@@ -94,6 +94,17 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
     for (int m = 0; m < DP; ++m) v = fmaf((float)A[m][i], (float)A[m][j], v);
     Mq[0][i][j] = v;
     cmax = fmaxf(cmax, fabsf(v));
+  }
+  {   // |mu_k - center|: a tile whose sphere holds every component's mean keeps every component (fullcov_bounds)
+    const float dmu = j < D ? mu[j] - (center ? center[j] : 0.f) : 0.f;
+    __syncthreads();
+    red[j] = dmu * dmu;
+    __syncthreads();
+    if (j == 0) {
+      float t = 0.f;
+      for (int i = 0; i < DP; ++i) t += red[i];
+      mudist[c * K + k] = sqrtf(t);
+    }
   }
   float scale[4];
   scale[0] = block_max(cmax);
@@ -172,39 +183,119 @@ __global__ __launch_bounds__(256) void fullcov_tilestats(const float* __restrict
   if (lane == 0) out[DP] = sqrtf(dist2);
 }
 
-// Which components a tile can leave out.  For a row y of the tile and u_k(y) = A_k (y - mu_k):
-//   | |u_k(y)| - |u_k(m)| | <= |A_k|_2 |y - m| <= anorm_k r      (m, r: the tile's centre and radius)
+// Spheres around groups of 64 consecutive tiles: centre = mean of the tiles' centres, radius = the largest
+// (distance of a tile's centre + that tile's radius).  Same layout as tstat.  One wave per group, lane = tile.
+__global__ __launch_bounds__(64) void fullcov_groupstats(const float* __restrict__ tstat, int64_t ntiles,
+                                                         float* __restrict__ gstat) {
+  const int lane = threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+  const bool tv = t < ntiles;
+  const float* ts = tstat + (tv ? t : 0) * (DP + 1);
+  const float nv = (float)__builtin_popcountll(__builtin_amdgcn_ballot_w64(tv));
+  float e2 = 0.f;
+  float* out = gstat + (int64_t)blockIdx.x * (DP + 1);
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    const float x = ts[d];
+    float v = tv ? x : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const float m = v / nv;
+    if (lane == d) out[d] = m;
+    const float e = x - m;
+    e2 = fmaf(e, e, e2);
+  }
+  float rs = tv ? sqrtf(e2) + ts[DP] : 0.f;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(rs, off, 64);
+    rs = (o > rs || o != o) ? o : rs;                    // NaN wins: such a group keeps every component
+  }
+  if (lane == 0) out[DP] = rs;
+}
+
+// Which components a sphere of rows (a tile, or a group of 64 tiles) can leave out.  For a row y in the sphere and
+// u_k(y) = A_k (y - mu_k):
+//   | |u_k(y)| - |u_k(m)| | <= |A_k|_2 |y - m| <= anorm_k r      (m, r: the sphere's centre and radius)
 // so a_k(y) = cst_k - |u_k(y)|^2 / 2 lies between cst_k - hi_k^2 / 2 and cst_k - lo_k^2 / 2 with
 // hi / lo = |u_k(m)| +- anorm_k r.  A component whose upper bound is more than 32 below the largest lower bound has
-// responsibilities below e^-32 = 2^-46 for every row of the tile: bit k of tmask[chain][tile] is cleared and the
-// streaming kernel does not evaluate it there (its terms are below the 2^-40 the raw-sums phase keeps anyway).
-// Anything non-finite keeps the bit set.  One thread per tile; A_k, b_k come through the scalar cache (read-only,
-// the same address in every lane).
+// responsibilities below e^-32 = 2^-46 for every row of the sphere: bit k of mask[chain][sphere] is cleared and the
+// streaming kernels do not evaluate it there (its terms are below the 2^-40 the raw-sums phase keeps anyway).
+// Anything non-finite keeps the bit set.  One thread per sphere:
+//   1. without any product: |u_k(m)| <= anorm_k (|m - centre| + |mu_k - centre|) bounds lo_k from above and
+//      hi_j >= anorm_j r bounds the largest lower bound from above; if that already keeps every component (rows in
+//      no particular order: r is the size of the whole dataset) the sphere is done;
+//   2. the test itself, only for the components the sphere's group kept (`parent`, one mask per 64 spheres: with
+//      rows stored cluster by cluster most components are ruled out for 64 tiles at once).
 __global__ __launch_bounds__(256) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K,
                                                       const float* __restrict__ Ainv, const float* __restrict__ bvec,
                                                       const float* __restrict__ cst, const float* __restrict__ anorm,
+                                                      const float* __restrict__ mudist,
                                                       const float* __restrict__ center, int C,
-                                                      unsigned short* __restrict__ tmask) {
-  const int c = blockIdx.y;
+                                                      const unsigned short* __restrict__ parent, int64_t nparent,
+                                                      unsigned short* __restrict__ mask_out) {
+  const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   __shared__ float aub[16][256];
-  if (t >= ntiles) return;
-  const float* ts = tstat + t * (DP + 1);
+  __shared__ __attribute__((aligned(16))) float As[DP * DP];
+  __shared__ float bs[DP];
+  __shared__ unsigned supw[4];
+  const bool tv = t < ntiles;
+  const float* ts = tstat + (tv ? t : 0) * (DP + 1);
   float dm[DP];
+  float dn2 = 0.f;
 #pragma unroll
-  for (int d = 0; d < DP; ++d) dm[d] = ts[d] - center[d];
+  for (int d = 0; d < DP; ++d) {
+    dm[d] = ts[d] - center[d];
+    dn2 = fmaf(dm[d], dm[d], dn2);
+  }
   const float r = ts[DP];
+  const unsigned full = (1u << K) - 1u;
+  // 1.
+  bool keeps_all = true;
+  {
+    const float dn = sqrtf(dn2);
+    float top = -INFINITY, low = INFINITY;            // upper bound of the largest lower bound; smallest a_ub bound
+    for (int k = 0; k < K; ++k) {
+      const float an = anorm[c * K + k], ck = cst[c * K + k];
+      const float sl = an * r;
+      const float lomax = fmaxf(an * (dn + mudist[c * K + k]) * 1.001f + 1e-3f - sl, 0.f);
+      top = fmaxf(top, ck - 0.5f * sl * sl);
+      low = fminf(low, ck - 0.5f * lomax * lomax);
+    }
+    keeps_all = !(low < top - 30.f);                  // (NaN: keeps everything)
+  }
+  // 2.  The components this wave's 64 spheres still have to test (they share a parent); A_k goes through LDS, one
+  //     component at a time for the whole workgroup (every lane reads the same element: a broadcast read).
+  unsigned sup = 0;
+  if (__builtin_amdgcn_ballot_w64(tv && !keeps_all) != 0) {
+    sup = full;
+    if (parent) sup = __builtin_amdgcn_readfirstlane((unsigned)parent[(int64_t)c * nparent + (t - lane) / 64]) & full;
+  }
+  if (lane == 0) supw[wave] = sup;
+  __syncthreads();
+  const unsigned any = supw[0] | supw[1] | supw[2] | supw[3];
   float best = -INFINITY;
-  bool odd = false;                      // something is not finite: keep everything
+  bool odd = false;                      // something is not finite: keep everything the parent kept
   for (int k = 0; k < K; ++k) {
-    const float* A = Ainv + ((int64_t)c * K + k) * DP * DP;
-    const float* b = bvec + ((int64_t)c * K + k) * DP;
+    if (!((any >> k) & 1u)) continue;    // (the same for the whole workgroup)
+    __syncthreads();                     // the previous component's readers are done
+    *reinterpret_cast<f32x4*>(&As[4 * threadIdx.x]) =
+        *reinterpret_cast<const f32x4*>(Ainv + ((int64_t)c * K + k) * DP * DP + 4 * threadIdx.x);
+    if (threadIdx.x < DP) bs[threadIdx.x] = bvec[((int64_t)c * K + k) * DP + threadIdx.x];
+    __syncthreads();
+    if (!((sup >> k) & 1u)) continue;
     float d2 = 0.f;
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
-      float sacc = -b[i];
+      float sacc = -bs[i];
 #pragma unroll
-      for (int j = 0; j <= i; ++j) sacc = fmaf(A[i * DP + j], dm[j], sacc);
+      for (int j4 = 0; j4 <= i; j4 += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[i * DP + j4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (j4 + e <= i) sacc = fmaf(a4[e], dm[j4 + e], sacc);
+      }
       d2 = fmaf(sacc, sacc, d2);
     }
     const float dk = sqrtf(d2), slack = anorm[c * K + k] * r * 1.001f + 1e-3f;
@@ -218,8 +309,9 @@ __global__ __launch_bounds__(256) void fullcov_bounds(const float* __restrict__ 
   const float thresh = best - 32.f - 1e-4f * fabsf(best);
   unsigned mask = 0;
   for (int k = 0; k < K; ++k)
-    if (odd || !(aub[k][threadIdx.x] < thresh)) mask |= 1u << k;
-  tmask[(int64_t)c * ntiles + t] = (unsigned short)mask;
+    if (((sup >> k) & 1u) && (odd || !(aub[k][threadIdx.x] < thresh))) mask |= 1u << k;
+  if (keeps_all) mask = full;
+  if (tv) mask_out[(int64_t)c * ntiles + t] = (unsigned short)mask;
 }
 
 // The level a typical row's log-density sits at, from the components' constants as the kernels hold them (floats):
@@ -572,9 +664,11 @@ __host__ __device__ __forceinline__ int fullcov_replicas(int K) { return K <= 1 
 // q < 2) = the tiles that ONE component reaches, namely component (w % K8) + FW q, and that wave w of
 // fullcov_single_kernel takes (with replicated components the replicas take turns); list 2 FW = the tiles several
 // components reach (fullcov_f16_kernel).  tlist[(chain, block)][cap] holds the lists back to back,
-// toff[(chain, block)][kListOffs] their starts and the end.  tmask == nullptr: every tile is reached by all K
+// toff[(chain, block)][kListOffs] their starts, the end, and one flag: whether the masks leave out at least an eighth
+// of the (tile, component) pairs of the last list -- then the instantiation of fullcov_f16_kernel that looks at the
+// masks takes this (chain, block), otherwise the one without that code (which is a tenth faster on full masks).  tmask == nullptr: every tile is reached by all K
 // components.  One wave per (chain, block), 64 tiles per step, positions from ballots.
-constexpr int kLists = 2 * FW + 1, kListOffs = kLists + 1;
+constexpr int kLists = 2 * FW + 1, kListOffs = kLists + 2;   // starts, end, and the mode of the last list
 __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __restrict__ tmask, int64_t ntiles, int K,
                                                         int cap, int* __restrict__ tlist, int* __restrict__ toff) {
   const int c = blockIdx.y, b = blockIdx.x, nb = gridDim.x, lane = threadIdx.x;
@@ -583,12 +677,16 @@ __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __
   int* seg = tlist + ((int64_t)c * nb + b) * cap;
   int* so = toff + ((int64_t)c * nb + b) * kListOffs;
   const int cnt_tiles = b < ntiles ? (int)((ntiles - b + nb - 1) / nb) : 0;
+  int saved = 0;                                      // (tile, component) pairs of the last list the masks leave out
   auto classify = [&](int i, int& entry) -> int {     // i-th tile of this block; returns its list, -1 past the end
     if (i >= cnt_tiles) return -1;
     const int64_t t = b + (int64_t)i * nb;
     const unsigned m = tmask ? (tmask[(int64_t)c * ntiles + t] & kmask) : kmask;
     entry = (int)t;
-    if (__builtin_popcount(m) != 1) return 2 * FW;
+    if (__builtin_popcount(m) != 1) {
+      saved += K - __builtin_popcount(m);
+      return 2 * FW;
+    }
     const int k = __builtin_ctz(m);
     return (k % FW) % K8 + K8 * (i % R) + (k >= FW ? FW : 0);
   };
@@ -604,11 +702,15 @@ __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __
   int start[kLists], run = 0;
 #pragma unroll
   for (int j = 0; j < kLists; ++j) { start[j] = run; run += count[j]; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) saved += __shfl_xor(saved, off, 64);
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < kLists; ++j) so[j] = start[j];
     so[kLists] = run;
+    so[kLists + 1] = (tmask != nullptr && saved * 8 >= K * count[kLists - 1] && saved > 0) ? 1 : 0;
   }
+  saved = 0;
   for (int i0 = 0; i0 < cnt_tiles; i0 += 64) {
     int e = 0;
     const int cl = classify(i0 + lane, e);
@@ -622,7 +724,9 @@ __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __
 }
 
 // GRAD = false (value only, what random-walk Metropolis asks for): no responsibilities, no raw sums
-template <int KQ, bool GRAD>  // components per wave (K <= FW * KQ)
+// PRUNE: the instantiation that looks at the tiles' component masks; each (chain, row block) is done by the one its
+// flag names (fullcov_tilelists), the other returns at once
+template <int KQ, bool GRAD, bool PRUNE>  // components per wave (K <= FW * KQ)
 __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD ? 2 : 4))) void fullcov_f16_kernel(
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
@@ -642,6 +746,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   const bool lead_wave = __builtin_amdgcn_readfirstlane(wave) < FW / 2;      // wave-uniform, in a scalar register
   const int ln = lane & 15, g = lane >> 4;
   const int c = blockIdx.y;
+  if ((toff[((int64_t)c * gridDim.x + blockIdx.x) * kListOffs + kLists + 1] != 0) != PRUNE) return;
   auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };
 
   // A''_k as B operand of GEMM1 (k = input dim, n = output dim): lane holds output dim 16 nt + ln, input dims
@@ -746,7 +851,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   const int li1 = so[kLists];
   int li = so[kLists - 1];
   // bit k of a tile's mask clear: component k is out of reach of every row of the tile (fullcov_bounds)
-  const unsigned short* tm = tmask ? tmask + (int64_t)c * ntiles : nullptr;
+  const unsigned short* tm = (PRUNE && tmask) ? tmask + (int64_t)c * ntiles : nullptr;
   unsigned mask_cur = 0xFFFFu, mask_nxt = 0xFFFFu;
   int64_t tile = 0, tile_nxt = 0;
   if (li < li1) {
@@ -768,7 +873,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     mask_cur = mask_nxt;
     bool act[KQ];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) act[q] = wave + FW * q < K && ((tile_mask >> (wave + FW * q)) & 1u) != 0;
+    for (int q = 0; q < KQ; ++q) act[q] = !PRUNE || (wave + FW * q < K && ((tile_mask >> (wave + FW * q)) & 1u) != 0);
     const unsigned char* yh = ybuf[buf][0];
     const unsigned char* yl = ybuf[buf][1];
     // ---- GEMM1: u = A (y - mu) for the wave's components, rows 4 g + i of each 16-row tile in registers ----
@@ -876,16 +981,20 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    if constexpr (KQ == 1) {
+    if constexpr (!PRUNE) {
+      gemm1(I0{}, std::integral_constant<int, KQ>{});
+    } else if constexpr (KQ == 1) {
       if (act[0]) gemm1(I0{}, I1{});
     } else {
       if (act[0] && act[1]) gemm1(I0{}, I2{});
       else if (act[0]) gemm1(I0{}, I1{});
       else if (act[1]) gemm1(I1{}, I1{});
     }
+    if constexpr (PRUNE) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q)
-      if (!act[q] && wave + FW * q < K) al[wave + FW * q][lane] = -INFINITY;
+      for (int q = 0; q < KQ; ++q)
+        if (!act[q] && wave + FW * q < K) al[wave + FW * q][lane] = -INFINITY;
+    }
     __syncthreads();
     {
       // log-sum-exp over the components and sqrt(rho_ik) = exp((a_ik - lse) / 2), shared out over the workgroup: wave w
@@ -1381,7 +1490,8 @@ int fullcov_list_cap(int64_t n, int nb) {
 size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t ntiles = (size_t)((n + FT - 1) / FT);
   const size_t nb = (size_t)fullcov_blocks(n, c);
-  return ntiles * (DP + 1) + (size_t)c * k + ((size_t)c * ntiles + 1) / 2 + 2 +
+  const size_t ngroups = (ntiles + 63) / 64;
+  return (ntiles + ngroups) * (DP + 1) + 2 * (size_t)c * k + ((size_t)c * (ntiles + ngroups) + 1) / 2 + 2 +
          (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
 }
 
@@ -1412,9 +1522,13 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   const int nblk = fullcov_blocks(n, c), reps = fullcov_replicas(k), cap = fullcov_list_cap(n, nblk);
   const size_t pstride = (size_t)c * ((size_t)k * (1 + DP + DP * DP) + 1);
   float* tstat = partials + (size_t)nblk * (1 + reps) * pstride;
-  float* anorm = tstat + (size_t)ntiles * (DP + 1);
-  unsigned short* tmask = reinterpret_cast<unsigned short*>(anorm + (size_t)c * k);
-  int* tlist = reinterpret_cast<int*>(anorm + (size_t)c * k + ((size_t)c * ntiles + 1) / 2 + 2);
+  const int64_t ngroups = (ntiles + 63) / 64;
+  float* gstat = tstat + (size_t)ntiles * (DP + 1);
+  float* anorm = gstat + (size_t)ngroups * (DP + 1);
+  float* mudist = anorm + (size_t)c * k;
+  unsigned short* tmask = reinterpret_cast<unsigned short*>(mudist + (size_t)c * k);
+  unsigned short* gmask = tmask + (size_t)c * ntiles;
+  int* tlist = reinterpret_cast<int*>(mudist + (size_t)c * k + ((size_t)c * (ntiles + ngroups) + 1) / 2 + 2);
   int* toff = tlist + (size_t)c * nblk * cap;
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
@@ -1424,7 +1538,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   dim3 grid(nb, c);
   if (use_f32) {
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)nullptr, Ainv,
-                       bvec, (float*)nullptr, cst, (float*)nullptr);
+                       bvec, (float*)nullptr, cst, (float*)nullptr, (float*)nullptr);
     BVI_HIP_CHECK_LAUNCH();
     const int kq = bvi_ceil_div(k, 4);
     const size_t lds = ((size_t)k * DP * LS + (size_t)k * DP + TR * LS + 4 * kq * TR + TR + 4 * kq) * sizeof(float);
@@ -1450,13 +1564,17 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     static const bool no_prune = getenv("BVI_FULLCOV_NO_PRUNE") && atoi(getenv("BVI_FULLCOV_NO_PRUNE")) != 0;
     const bool prune = k > 1 && ntiles > 0 && !no_prune;
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
-                       bvec, blo, cst, prune ? anorm : (float*)nullptr);
+                       bvec, blo, cst, prune ? anorm : (float*)nullptr, mudist);
     BVI_HIP_CHECK_LAUNCH();
     if (prune) {
       hipLaunchKernelGGL(fullcov_tilestats, dim3((unsigned)bvi_ceil_div(ntiles, 4)), dim3(256), 0, s, Y, n, d, ntiles, tstat);
+      hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
+      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 256), c), dim3(256), 0, s, (const float*)gstat,
+                         ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
+                         (const float*)mudist, (const float*)center, c, (const unsigned short*)nullptr, (int64_t)0, gmask);
       hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ntiles, 256), c), dim3(256), 0, s, (const float*)tstat,
                          ntiles, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
-                         (const float*)center, c, tmask);
+                         (const float*)mudist, (const float*)center, c, (const unsigned short*)gmask, ngroups, tmask);
       BVI_HIP_CHECK_LAUNCH();
     }
     const unsigned short* tmask_arg = prune ? tmask : nullptr;
@@ -1465,10 +1583,13 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     hipLaunchKernelGGL(fullcov_tilelists, dim3(nblk, c), dim3(64), 0, s, lists_from_masks ? tmask_arg : (const unsigned short*)nullptr,
                        ntiles, lists_from_masks ? k : 16, cap, tlist, toff);
     BVI_HIP_CHECK_LAUNCH();
-#define BVI_FC16(KQ, GRAD)                                                                                          \
-  hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,           \
+#define BVI_FC16D(KQ, GRAD, PRUNE)                                                                                  \
+  hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD, PRUNE>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,    \
                      (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
-                     c, partials, tmask_arg, (const int*)tlist, (const int*)toff, cap);                                     \
+                     c, partials, tmask_arg, (const int*)tlist, (const int*)toff, cap)
+#define BVI_FC16(KQ, GRAD)                                                                                          \
+  BVI_FC16D(KQ, GRAD, false);                                                                                        \
+  if (prune) BVI_FC16D(KQ, GRAD, true);                                                                              \
   hipLaunchKernelGGL((fullcov_single_kernel<GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,            \
                      (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
                      c, partials + (size_t)nblk * pstride, (const int*)tlist, (const int*)toff, cap)
@@ -1478,6 +1599,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
       if (grad) { BVI_FC16(2, true); } else { BVI_FC16(2, false); }
     }
 #undef BVI_FC16
+#undef BVI_FC16D
     nb_total = nblk * (1 + reps);
   }
   BVI_HIP_CHECK_LAUNCH();
