@@ -37,8 +37,7 @@ constexpr int TR = 16;        // rows per tile
 
 __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, int D,
                                 const float* __restrict__ center, float* __restrict__ Ainv,
-                                float* __restrict__ bvec, float* __restrict__ blo, float* __restrict__ cst,
-                                float* __restrict__ anorm, float* __restrict__ mudist) {
+                                float* __restrict__ bvec, float* __restrict__ blo, float* __restrict__ cst) {
   // blo: optional low part of b (b = bvec + blo to ~2^-48): b is common to all rows of a component, so its
   // rounding error would add up coherently over the rows
   // center: optional per-column shift the streaming kernel applies to the data (b = A (mu - center))
@@ -74,62 +73,67 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
     for (int m = 0; m < D; ++m) ld += log((double)L[m * D + m]);
     cst[c * K + k] = (float)(log((double)th[k]) - log(wsum) - ld - 0.5 * D * BVI_LN2PI_D);
   }
-  if (!anorm) return;
-  // An upper bound of the spectral norm of A, for the far-component test of the streaming kernel (fullcov_bounds):
-  // |A|_2^2 = lambda_max(M), M = A^T A, and lambda_max(M)^8 = lambda_max(M^8) <= |M^8|_F, which is within
-  // DP^(1/16) = 1.24 of it.  Three squarings in float, each normalised by its largest entry (thread j owns column j).
-  __shared__ float Mq[2][DP][DP + 1];
-  __shared__ float red[DP];
-  auto block_max = [&](float v) {
+}
+
+// For the far-component test (fullcov_bounds), per chain and component:
+//   anorm  = an upper bound of the spectral norm of A: |A|_2^2 = lambda_max(M), M = A^T A, and lambda_max(M)^8 =
+//            lambda_max(M^8) <= |M^8|_F, which is within DP^(1/16) = 1.24 of it -- three squarings in float, each
+//            normalised by its largest entry;
+//   mudist = |mu_k - center|.
+// One workgroup of 256 threads per (chain, component): thread (rg, j) owns rows rg, rg + 8, ... of column j.
+__global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ theta, int K, int D,
+                                                     const float* __restrict__ center, const float* __restrict__ Ainv,
+                                                     float* __restrict__ anorm, float* __restrict__ mudist) {
+  const int c = blockIdx.x / K, k = blockIdx.x % K, tid = threadIdx.x, j = tid & (DP - 1), rg = tid / DP;
+  const int P = K + K * D + K * D * D;
+  const float* mu = theta + (int64_t)c * P + K + k * D;
+  __shared__ float Af[DP][DP + 1], Mq[2][DP][DP + 1];
+  __shared__ float red[4];
+  auto block_reduce = [&](float v, bool take_max) {     // NaN-blind maxima on purpose: the final sum carries a NaN through
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float o = __shfl_xor(v, off, 64);
+      v = take_max ? fmaxf(v, o) : v + o;
+    }
     __syncthreads();
-    red[j] = v;
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    float m = 0.f;
-    for (int i = 0; i < DP; ++i) m = fmaxf(m, red[i]);   // NaN-blind on purpose: the sum below carries a NaN through
-    return m;
+    return take_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
   };
+  const float* Ak = Ainv + ((int64_t)c * K + k) * DP * DP;
+  for (int i = rg; i < DP; i += 8) Af[i][j] = Ak[i * DP + j];
+  const float dmu = (rg == 0 && j < D) ? mu[j] - center[j] : 0.f;
+  const float md2 = block_reduce(dmu * dmu, false);     // (its barriers also publish Af)
+  if (tid == 0) mudist[c * K + k] = sqrtf(md2);
   float cmax = 0.f;
-  for (int i = 0; i < DP; ++i) {
+  for (int i = rg; i < DP; i += 8) {
     float v = 0.f;
-    for (int m = 0; m < DP; ++m) v = fmaf((float)A[m][i], (float)A[m][j], v);
+#pragma unroll
+    for (int m = 0; m < DP; ++m) v = fmaf(Af[m][i], Af[m][j], v);
     Mq[0][i][j] = v;
     cmax = fmaxf(cmax, fabsf(v));
   }
-  {   // |mu_k - center|: a tile whose sphere holds every component's mean keeps every component (fullcov_bounds)
-    const float dmu = j < D ? mu[j] - (center ? center[j] : 0.f) : 0.f;
-    __syncthreads();
-    red[j] = dmu * dmu;
-    __syncthreads();
-    if (j == 0) {
-      float t = 0.f;
-      for (int i = 0; i < DP; ++i) t += red[i];
-      mudist[c * K + k] = sqrtf(t);
-    }
-  }
   float scale[4];
-  scale[0] = block_max(cmax);
+  scale[0] = block_reduce(cmax, true);
   int cur = 0;
   for (int sq = 0; sq < 3; ++sq) {
     const float inv = scale[sq] > 0.f ? 1.f / scale[sq] : 0.f;
     cmax = 0.f;
-    for (int i = 0; i < DP; ++i) {
+    for (int i = rg; i < DP; i += 8) {
       float v = 0.f;
+#pragma unroll
       for (int m = 0; m < DP; ++m) v = fmaf(Mq[cur][i][m] * inv, Mq[cur][m][j] * inv, v);
       Mq[cur ^ 1][i][j] = v;
       cmax = fmaxf(cmax, fabsf(v));
     }
-    scale[sq + 1] = block_max(cmax);
+    scale[sq + 1] = block_reduce(cmax, true);
     cur ^= 1;
   }
   float fro = 0.f;
   const float inv = scale[3] > 0.f ? 1.f / scale[3] : 0.f;
-  for (int i = 0; i < DP; ++i) fro = fmaf(Mq[cur][i][j] * inv, Mq[cur][i][j] * inv, fro);
-  __syncthreads();
-  red[j] = fro;
-  __syncthreads();
-  if (j == 0) {
-    float f = 0.f;
-    for (int i = 0; i < DP; ++i) f += red[i];
+  for (int i = rg; i < DP; i += 8) fro = fmaf(Mq[cur][i][j] * inv, Mq[cur][i][j] * inv, fro);
+  const float f = block_reduce(fro, false);
+  if (tid == 0) {
     // lambda(M) <= s0 sqrt(s1 sqrt(s2 sqrt(s3 |N3|_F)))
     float lam = scale[3] * sqrtf(f);
     lam = scale[2] * sqrtf(lam);
@@ -139,48 +143,85 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
   }
 }
 
-// Centre (column means) and radius (largest distance of a row from the centre) of every 64-row tile, raw
-// coordinates: tstat[tile][0 .. DP-1] = centre, [DP] = radius.  One wave per tile, lane = row.
+// One pass over Y for both kinds of statistics.  Per 64-row tile: centre (column means) and radius (largest distance
+// of a row from the centre), raw coordinates: tstat[tile][0 .. DP-1] = centre, [DP] = radius (tstat == nullptr: not
+// wanted).  Per column: sum (double), min, max over the rows of this workgroup's tiles, psum / pmin / pmax[block][DP]
+// (the first stage of the column statistics; fullcov_colstats_final is the second).  One wave per tile, lane = row;
+// a workgroup's four waves stride over the tiles.
 __global__ __launch_bounds__(256) void fullcov_tilestats(const float* __restrict__ Y, int64_t n, int D, int64_t ntiles,
-                                                         float* __restrict__ tstat) {
-  const int lane = threadIdx.x & 63;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= ntiles) return;
-  const int64_t row = tile * 64 + lane;
-  const bool valid = row < n;
-  const int64_t left = n - tile * 64;
-  const float icnt = 1.f / (float)(left < 64 ? left : 64);
-  float y[DP];
-  if (D == DP && (((uintptr_t)Y & 15) == 0)) {
+                                                         float* __restrict__ tstat, double* __restrict__ psum,
+                                                         float* __restrict__ pmin, float* __restrict__ pmax) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vec_ok = D == DP && (((uintptr_t)Y & 15) == 0);
+  double csum = 0.0;                                   // lane d < DP: column d
+  float mn[DP], mx[DP];                                // this lane's rows
 #pragma unroll
-    for (int q = 0; q < DP / 4; ++q) {
-      f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-      if (valid) t4 = *reinterpret_cast<const f32x4*>(Y + row * DP + 4 * q);
+  for (int d = 0; d < DP; ++d) { mn[d] = INFINITY; mx[d] = -INFINITY; }
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t row = tile * 64 + lane;
+    const bool valid = row < n;
+    const int64_t left = n - tile * 64;
+    const float icnt = 1.f / (float)(left < 64 ? left : 64);
+    float y[DP];
+    if (vec_ok) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[4 * q + e] = t4[e];
+      for (int q = 0; q < DP / 4; ++q) {
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        if (valid) t4 = *reinterpret_cast<const f32x4*>(Y + row * DP + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[4 * q + e] = t4[e];
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DP; ++d) y[d] = (valid && d < D) ? Y[row * D + d] : 0.f;
     }
-  } else {
+    float dist2 = 0.f;
 #pragma unroll
-    for (int d = 0; d < DP; ++d) y[d] = (valid && d < D) ? Y[row * D + d] : 0.f;
+    for (int d = 0; d < DP; ++d) {
+      if (valid) { mn[d] = fminf(mn[d], y[d]); mx[d] = fmaxf(mx[d], y[d]); }
+      float sm = y[d];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
+      const float m = sm * icnt;
+      if (lane == d) {
+        csum += (double)sm;
+        if (tstat) tstat[tile * (DP + 1) + d] = m;
+      }
+      const float e = valid ? y[d] - m : 0.f;
+      dist2 = fmaf(e, e, dist2);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float o = __shfl_xor(dist2, off, 64);
+      dist2 = (o > dist2 || o != o) ? o : dist2;         // NaN wins: such a tile keeps every component
+    }
+    if (lane == 0 && tstat) tstat[tile * (DP + 1) + DP] = sqrtf(dist2);
   }
-  float dist2 = 0.f;
-  float* out = tstat + tile * (DP + 1);
+  // column minima / maxima over the wave's rows (lane d keeps column d), then over the four waves
+  float cmn = INFINITY, cmx = -INFINITY;
 #pragma unroll
   for (int d = 0; d < DP; ++d) {
-    float sm = y[d];
+    float a = mn[d], b = mx[d];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
-    const float m = sm * icnt;
-    if (lane == d) out[d] = m;
-    const float e = valid ? y[d] - m : 0.f;
-    dist2 = fmaf(e, e, dist2);
+    for (int off = 32; off >= 1; off >>= 1) {
+      a = fminf(a, __shfl_xor(a, off, 64));
+      b = fmaxf(b, __shfl_xor(b, off, 64));
+    }
+    if (lane == d) { cmn = a; cmx = b; }
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float o = __shfl_xor(dist2, off, 64);
-    dist2 = (o > dist2 || o != o) ? o : dist2;           // NaN wins: such a tile keeps every component
+  __shared__ double ssum[4][DP];
+  __shared__ float smn[4][DP], smx[4][DP];
+  if (lane < DP) { ssum[wave][lane] = csum; smn[wave][lane] = cmn; smx[wave][lane] = cmx; }
+  __syncthreads();
+  if (threadIdx.x < DP) {
+    const int d = threadIdx.x;
+    double t = ssum[0][d];
+    float a = smn[0][d], b = smx[0][d];
+    for (int w = 1; w < 4; ++w) { t += ssum[w][d]; a = fminf(a, smn[w][d]); b = fmaxf(b, smx[w][d]); }
+    psum[blockIdx.x * DP + d] = d < D ? t : 0.0;
+    pmin[blockIdx.x * DP + d] = a;
+    pmax[blockIdx.x * DP + d] = b;
   }
-  if (lane == 0) out[DP] = sqrtf(dist2);
 }
 
 // Spheres around groups of 64 consecutive tiles: centre = mean of the tiles' centres, radius = the largest
@@ -588,37 +629,8 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// column statistics of Y, stage 1: block b reduces rows b, b + nblk, ...: sum (double), min, max per column
-__global__ void fullcov_colstats(const float* __restrict__ Y, int64_t n, int D, double* __restrict__ psum,
-                                 float* __restrict__ pmin, float* __restrict__ pmax) {
-  // 256 threads = 8 row lanes x 32 columns
-  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  double sum = 0.0;
-  float mn = INFINITY, mx = -INFINITY;
-  if (col < D)
-    for (int64_t row = (int64_t)blockIdx.x * 8 + rl; row < n; row += (int64_t)gridDim.x * 8) {
-      const float v = Y[row * D + col];
-      sum += (double)v;
-      mn = fminf(mn, v);
-      mx = fmaxf(mx, v);
-    }
-  __shared__ double ssum[256];
-  __shared__ float smn[256], smx[256];
-  ssum[threadIdx.x] = sum; smn[threadIdx.x] = mn; smx[threadIdx.x] = mx;
-  __syncthreads();
-  if (rl == 0) {
-    for (int q = 1; q < 8; ++q) {
-      sum += ssum[q * 32 + col];
-      mn = fminf(mn, smn[q * 32 + col]);
-      mx = fmaxf(mx, smx[q * 32 + col]);
-    }
-    psum[blockIdx.x * DP + col] = sum;
-    pmin[blockIdx.x * DP + col] = mn;
-    pmax[blockIdx.x * DP + col] = mx;
-  }
-}
-
-// stage 2 (one workgroup of 256 threads = 8 groups x DP columns, each group folds every 8th partial):
+// column statistics, stage 2 (stage 1: fullcov_tilestats; one workgroup of 256 threads = 8 groups x DP columns, each
+// group folds every 8th partial):
 // center[d] = mean, cscale[d] = power-of-two scale of max |y - mean| (0 for a constant / unused column)
 __global__ __launch_bounds__(256) void fullcov_colstats_final(const double* __restrict__ psum,
                                                               const float* __restrict__ pmin,
@@ -746,7 +758,11 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   const bool lead_wave = __builtin_amdgcn_readfirstlane(wave) < FW / 2;      // wave-uniform, in a scalar register
   const int ln = lane & 15, g = lane >> 4;
   const int c = blockIdx.y;
-  if ((toff[((int64_t)c * gridDim.x + blockIdx.x) * kListOffs + kLists + 1] != 0) != PRUNE) return;
+  {
+    const int* so0 = toff + ((int64_t)c * gridDim.x + blockIdx.x) * kListOffs;
+    if ((so0[kLists + 1] != 0) != PRUNE) return;
+    if (so0[kLists - 1] == so0[kLists]) return;      // no tile of this kind: fullcov_finalize skips the block's partials
+  }
   auto swz = [](int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; };
 
   // A''_k as B operand of GEMM1 (k = input dim, n = output dim): lane holds output dim 16 nt + ln, input dims
@@ -1339,20 +1355,29 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {        // 32-row pairs: k index j <-> row 32 m + 16 (j >> 2) + 4 g + (j & 3)
-          float sr[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) sr[j] = all_ok ? 1.f : sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3)];
           f16x8 wh[2], wl[2];
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             unsigned hw[4], lw[4];
+            if (all_ok) {                    // every row counts in full (all but the last tile, usually): w = u
+#pragma unroll
+              for (int j = 0; j < 8; j += 2) {
+                const float w0 = u[2 * m + (j >> 2)][nt][j & 3];
+                const float w1 = u[2 * m + (j >> 2)][nt][(j & 3) + 1];
+                S1[nt] += w0 + w1;
+                fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
+              }
+            } else {
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-              const float w0 = sr[j] * u[2 * m + (j >> 2)][nt][j & 3];
-              const float w1 = sr[j + 1] * u[2 * m + (j >> 2)][nt][(j & 3) + 1];
-              S1[nt] = fmaf(sr[j], w0, S1[nt]);
-              S1[nt] = fmaf(sr[j + 1], w1, S1[nt]);
+              const float sr0 = sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3)];
+              const float sr1 = sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3) + 1];
+              const float w0 = sr0 * u[2 * m + (j >> 2)][nt][j & 3];
+              const float w1 = sr1 * u[2 * m + (j >> 2)][nt][(j & 3) + 1];
+              S1[nt] = fmaf(sr0, w0, S1[nt]);
+              S1[nt] = fmaf(sr1, w1, S1[nt]);
               fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
+            }
             }
             wh[nt] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
             wl[nt] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
@@ -1408,7 +1433,8 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
                                                            const float* __restrict__ Ainv,
                                                            const float* __restrict__ cst, int C,
                                                            float* __restrict__ logp, float* __restrict__ grad,
-                                                           const double* __restrict__ ref) {
+                                                           const double* __restrict__ ref,
+                                                           const int* __restrict__ toff, int nb_dense) {
   constexpr int Q = 1 + DP + DP * DP, RG = DP / 8;
   const int c = blockIdx.x / K, k = blockIdx.x % K, j = threadIdx.x & (DP - 1), ig = threadIdx.x / DP;
   const int P = K + K * D + K * D * D;
@@ -1418,6 +1444,11 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
   double col[RG];
   for (int r = 0; r < RG; ++r) col[r] = 0.0;
   for (int b = 0; b < nb; ++b) {
+    // a row block without tiles for the many-component kernel wrote nothing (the same for every thread)
+    if (toff && b < nb_dense) {
+      const int* so = toff + ((int64_t)c * nb_dense + b) * kListOffs;
+      if (so[kLists - 1] == so[kLists]) continue;
+    }
     const float* p = partials + ((int64_t)b * C + c) * stride + (int64_t)k * Q;
     if (grad) {                     // a value-only launch wrote the log-density partial only
       for (int r = 0; r < RG; ++r) col[r] += (double)p[1 + DP + (ig + 8 * r) * DP + j];
@@ -1475,7 +1506,7 @@ int fullcov_blocks(int64_t n, int c) {
 
 }  // namespace
 
-constexpr int kStatBlocks = 256;
+constexpr int kStatBlocks = 1024;
 // floats of workspace in front of everything else: column statistics of Y (doubles first: 8-B aligned)
 constexpr size_t kStatFloats = 2 * (size_t)kStatBlocks * DP + 2 * (size_t)kStatBlocks * DP + 2 * DP;
 
@@ -1538,7 +1569,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   dim3 grid(nb, c);
   if (use_f32) {
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)nullptr, Ainv,
-                       bvec, (float*)nullptr, cst, (float*)nullptr, (float*)nullptr);
+                       bvec, (float*)nullptr, cst);
     BVI_HIP_CHECK_LAUNCH();
     const int kq = bvi_ceil_div(k, 4);
     const size_t lds = ((size_t)k * DP * LS + (size_t)k * DP + TR * LS + 4 * kq * TR + TR + 4 * kq) * sizeof(float);
@@ -1557,17 +1588,18 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     }
 #undef BVI_FC_CASE
   } else {
-    hipLaunchKernelGGL(fullcov_colstats, dim3(kStatBlocks), dim3(256), 0, s, Y, n, d, psum, pmin, pmax);
+    static const bool no_prune = getenv("BVI_FULLCOV_NO_PRUNE") && atoi(getenv("BVI_FULLCOV_NO_PRUNE")) != 0;
+    const bool prune = k > 1 && ntiles > 0 && !no_prune;       // one component: nothing to leave out
+    hipLaunchKernelGGL(fullcov_tilestats, dim3(kStatBlocks), dim3(256), 0, s, Y, n, d, ntiles,
+                       prune ? tstat : (float*)nullptr, psum, pmin, pmax);
     hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(256), 0, s, (const double*)psum, (const float*)pmin,
                        (const float*)pmax, kStatBlocks, n, d, center, cscale);
-    // one component: nothing to leave out
-    static const bool no_prune = getenv("BVI_FULLCOV_NO_PRUNE") && atoi(getenv("BVI_FULLCOV_NO_PRUNE")) != 0;
-    const bool prune = k > 1 && ntiles > 0 && !no_prune;
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
-                       bvec, blo, cst, prune ? anorm : (float*)nullptr, mudist);
+                       bvec, blo, cst);
     BVI_HIP_CHECK_LAUNCH();
     if (prune) {
-      hipLaunchKernelGGL(fullcov_tilestats, dim3((unsigned)bvi_ceil_div(ntiles, 4)), dim3(256), 0, s, Y, n, d, ntiles, tstat);
+      hipLaunchKernelGGL(fullcov_anorm, dim3(c * k), dim3(256), 0, s, theta, k, d, (const float*)center, (const float*)Ainv,
+                         anorm, mudist);
       hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
       hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 256), c), dim3(256), 0, s, (const float*)gstat,
                          ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
@@ -1604,7 +1636,8 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   }
   BVI_HIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(fullcov_finalize, dim3(c * k), dim3(8 * DP), 0, s, (const float*)partials, nb_total, n, d, k, theta,
-                     (const float*)Ainv, use_f32 ? (const float*)nullptr : (const float*)cst, c, logp, grad, logp_ref);
+                     (const float*)Ainv, use_f32 ? (const float*)nullptr : (const float*)cst, c, logp, grad, logp_ref,
+                     use_f32 ? (const int*)nullptr : (const int*)toff, nb);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
 }
