@@ -217,6 +217,12 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
  * diagonal ignored) -> logp[C], grad[C, same layout] (gradient of scale_tril is lower triangular).
  * d <= 32, k <= 16; f16-piece arithmetic on the matrix cores (data in 2 pieces, centred and range-normalised
  * per column by a statistics pass per call; whitening matrices in 3 pieces: exact), f32 accumulation.
+ * The rows may come in any order.  Per call the library bounds, for every 64-row tile (centre and radius of its rows)
+ * and every chain, each component's log-density over the tile (spectral-norm bound of the whitening matrix) and does
+ * not evaluate a component on a tile where its responsibility is below 2^-46 for every row; tiles only one component
+ * reaches are summed without a log-sum-exp.  A caller that stores neighbouring rows next to each other (the shipped
+ * host layer orders its copy cluster by cluster) gets most tiles of that kind: N = 1M, D = 32, K = 16, 64 chains
+ * 2.2 ms against 13.8 ms for rows in no particular order.  What is left out is below 2^-40 of any sum.
  * Replaces the likelihood node
  * MixtureSameFamily(Categorical(probs), MultivariateNormalTriL(locs, scale_tril)) of
  * exploratory_experiments/multivariate-gaussian-mixture-density-estimation-test.ipynb cell 7. */

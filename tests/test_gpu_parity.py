@@ -655,6 +655,53 @@ def test_gmm_fullcov_rows_stored_cluster_by_cluster(nat, ws, gpu_device, d, k):
         assert_grad_close(g.cpu().numpy(), ref_g, term_scale=np.full_like(ref_g, 3.0 * n))
 
 
+@pytest.mark.parametrize('d,k,n,spread,pair_gap', [(32, 16, 6000 + 17, 1.0, None), (8, 2, 4096 + 5, 1.0, None),
+                                                     (5, 3, 3000, 0.7, None), (16, 4, 5000, 1.0, None),
+                                                     (32, 16, 8000, 1.0, 3.0), (8, 6, 5003, 1.0, 2.5),
+                                                     (32, 12, 70, 1.0, None)])
+def test_gmm_fullcov_tile_kinds(nat, ws, gpu_device, d, k, n, spread, pair_gap):
+    """The three ways a 64-row tile is evaluated, against the float64 oracle, on rows stored cluster by cluster:
+    tiles one component reaches (a kernel of their own: no log-sum-exp; with K <= 4 the components are replicated over
+    the waves; a row count that is not a multiple of 64 puts rows of weight 0 into its last tile), tiles several
+    components reach with some ruled out (`pair_gap`: the components come in pairs a few widths apart, so every tile
+    is reached by two of them), and tiles every component reaches (a chain whose components all sit on the data's
+    centre).  One chain has a non-finite parameter: its outputs are non-finite, the others' are untouched."""
+    from bayes_vi_amd.fused_target import cluster_row_order
+    rng = np.random.default_rng(1000 * d + 10 * k + n % 97)
+    true_mu = rng.integers(-20, 21, (k, d)).astype(np.float64)
+    if pair_gap is not None:
+        for j in range(1, k, 2):
+            true_mu[j] = true_mu[j - 1] + pair_gap * spread * rng.normal(size=d) / np.sqrt(d)
+    comp = rng.integers(0, k, n)
+    Y = (true_mu[comp] + spread * rng.normal(size=(n, d))).astype(np.float32)
+    c = 4
+    w = rng.dirichlet(np.ones(k) * 5, c).astype(np.float32)
+    mu = (true_mu[None] + rng.normal(0, 0.1 * spread, (c, k, d))).astype(np.float32)
+    mu[2] = Y.mean(0) + rng.normal(0, 0.05, (k, d))           # chain 2: every component in the middle of everything
+    L = np.tril(rng.normal(size=(c, k, d, d)) * 0.03 * spread)
+    for i in range(d):
+        L[..., i, i] = spread * rng.uniform(0.9, 1.2, (c, k))
+    L[2] *= 8.0
+    L = L.astype(np.float32)
+    theta = np.concatenate([w, mu.reshape(c, -1), L.reshape(c, -1)], -1)
+    ref_lp, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+    ref_g = np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
+    theta[3, k + 1] = np.nan                                   # chain 3: one mean is not a number
+    Yd = dev(Y, gpu_device)
+    rows = Yd[cluster_row_order(Yd, k)].contiguous() if n >= 256 else Yd
+    lp, g = nat.gmm_fullcov_logp_grad(rows, dev(theta, gpu_device), k, ws)
+    lp, g = lp.cpu().numpy(), g.cpu().numpy()
+    assert_logp_close(lp[:3], ref_lp[:3])
+    assert_grad_close(g[:3], ref_g[:3], term_scale=np.full_like(ref_g[:3], 3.0 * n))
+    assert not np.isfinite(lp[3])
+    lpv, none = nat.gmm_fullcov_logp_grad(rows, dev(theta, gpu_device), k, ws, want_grad=False)
+    assert none is None
+    np.testing.assert_array_equal(lpv.cpu().numpy()[:3], lp[:3])
+    # the same call again: bit-identical (fixed order of every sum)
+    lp2, g2 = nat.gmm_fullcov_logp_grad(rows, dev(theta, gpu_device), k, ws)
+    assert np.array_equal(lp2.cpu().numpy()[:3], lp[:3]) and np.array_equal(g2.cpu().numpy()[:3], g[:3])
+
+
 def test_logp_rebase_and_reference_level(nat, ws, gpu_device):
     """bvi_logp_rebase: the largest finite stored log-density becomes 0, the level takes it (split over the row
     shards), the absolute values come back, non-finite entries stay what they are; and a likelihood entry point
