@@ -268,19 +268,18 @@ __global__ __launch_bounds__(64) void fullcov_groupstats(const float* __restrict
 //      no particular order: r is the size of the whole dataset) the sphere is done;
 //   2. the test itself, only for the components the sphere's group kept (`parent`, one mask per 64 spheres: with
 //      rows stored cluster by cluster most components are ruled out for 64 tiles at once).
-__global__ __launch_bounds__(256) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K,
+__global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K,
                                                       const float* __restrict__ Ainv, const float* __restrict__ bvec,
                                                       const float* __restrict__ cst, const float* __restrict__ anorm,
                                                       const float* __restrict__ mudist,
                                                       const float* __restrict__ center, int C,
                                                       const unsigned short* __restrict__ parent, int64_t nparent,
                                                       unsigned short* __restrict__ mask_out) {
-  const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  __shared__ float aub[16][256];
+  const int c = blockIdx.y, lane = threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  __shared__ float aub[16][64];
   __shared__ __attribute__((aligned(16))) float As[DP * DP];
   __shared__ float bs[DP];
-  __shared__ unsigned supw[4];
   const bool tv = t < ntiles;
   const float* ts = tstat + (tv ? t : 0) * (DP + 1);
   float dm[DP];
@@ -307,25 +306,23 @@ __global__ __launch_bounds__(256) void fullcov_bounds(const float* __restrict__ 
     keeps_all = !(low < top - 30.f);                  // (NaN: keeps everything)
   }
   // 2.  The components this wave's 64 spheres still have to test (they share a parent); A_k goes through LDS, one
-  //     component at a time for the whole workgroup (every lane reads the same element: a broadcast read).
+  //     component at a time (every lane reads the same element: a broadcast read).
   unsigned sup = 0;
   if (__builtin_amdgcn_ballot_w64(tv && !keeps_all) != 0) {
     sup = full;
     if (parent) sup = __builtin_amdgcn_readfirstlane((unsigned)parent[(int64_t)c * nparent + (t - lane) / 64]) & full;
   }
-  if (lane == 0) supw[wave] = sup;
-  __syncthreads();
-  const unsigned any = supw[0] | supw[1] | supw[2] | supw[3];
   float best = -INFINITY;
   bool odd = false;                      // something is not finite: keep everything the parent kept
   for (int k = 0; k < K; ++k) {
-    if (!((any >> k) & 1u)) continue;    // (the same for the whole workgroup)
+    if (!((sup >> k) & 1u)) continue;    // (the same for the whole wave)
     __syncthreads();                     // the previous component's readers are done
-    *reinterpret_cast<f32x4*>(&As[4 * threadIdx.x]) =
-        *reinterpret_cast<const f32x4*>(Ainv + ((int64_t)c * K + k) * DP * DP + 4 * threadIdx.x);
-    if (threadIdx.x < DP) bs[threadIdx.x] = bvec[((int64_t)c * K + k) * DP + threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(&As[4 * (lane + 64 * q)]) =
+          *reinterpret_cast<const f32x4*>(Ainv + ((int64_t)c * K + k) * DP * DP + 4 * (lane + 64 * q));
+    if (lane < DP) bs[lane] = bvec[((int64_t)c * K + k) * DP + lane];
     __syncthreads();
-    if (!((sup >> k) & 1u)) continue;
     float d2 = 0.f;
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
@@ -629,29 +626,30 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// column statistics, stage 2 (stage 1: fullcov_tilestats; one workgroup of 256 threads = 8 groups x DP columns, each
-// group folds every 8th partial):
+// column statistics, stage 2 (stage 1: fullcov_tilestats; one workgroup of 1024 threads = 32 groups x DP columns, each
+// group folds every 32nd partial, always in the same order):
 // center[d] = mean, cscale[d] = power-of-two scale of max |y - mean| (0 for a constant / unused column)
-__global__ __launch_bounds__(256) void fullcov_colstats_final(const double* __restrict__ psum,
+__global__ __launch_bounds__(1024) void fullcov_colstats_final(const double* __restrict__ psum,
                                                               const float* __restrict__ pmin,
                                                               const float* __restrict__ pmax, int nblk, int64_t n,
                                                               int D, float* __restrict__ center,
                                                               float* __restrict__ cscale) {
-  static_assert(DP == 32, "8 groups x 32 columns");
+  static_assert(DP == 32, "32 groups x 32 columns");
+  constexpr int NG = 32;
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   double sum = 0.0;
   float mn = INFINITY, mx = -INFINITY;
-  for (int b = grp; b < nblk; b += 8) {
+  for (int b = grp; b < nblk; b += NG) {
     sum += psum[b * DP + col];
     mn = fminf(mn, pmin[b * DP + col]);
     mx = fmaxf(mx, pmax[b * DP + col]);
   }
-  __shared__ double ssum[8][DP];
-  __shared__ float smn[8][DP], smx[8][DP];
+  __shared__ double ssum[NG][DP];
+  __shared__ float smn[NG][DP], smx[NG][DP];
   ssum[grp][col] = sum; smn[grp][col] = mn; smx[grp][col] = mx;
   __syncthreads();
   if (grp != 0) return;
-  for (int q = 1; q < 8; ++q) {
+  for (int q = 1; q < NG; ++q) {
     sum += ssum[q][col];
     mn = fminf(mn, smn[q][col]);
     mx = fmaxf(mx, smx[q][col]);
@@ -1497,16 +1495,19 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
   }
 }
 
-int fullcov_blocks(int64_t n, int c) {
+int fullcov_blocks(int64_t n, int c, bool grad = false) {
   int nb = bvi_ceil_div(n, 4 * TR);
-  const int cap = c >= 512 ? 1 : 512 / c;   // ~2 workgroups per CU over all chains
+  // workgroups per CU over all chains: 2 for the value-only kernels (two fit), 1 with the gradient (one fits: a second
+  // round would pay the prologue and the partial sums twice); sizes are taken for the larger of the two
+  const int per = grad ? 256 : 512;
+  const int cap = c >= per ? 1 : per / c;
   if (nb > cap) nb = cap;
   return nb < 1 ? 1 : nb;
 }
 
 }  // namespace
 
-constexpr int kStatBlocks = 1024;
+constexpr int kStatBlocks = 2048;
 // floats of workspace in front of everything else: column statistics of Y (doubles first: 8-B aligned)
 constexpr size_t kStatFloats = 2 * (size_t)kStatBlocks * DP + 2 * (size_t)kStatBlocks * DP + 2 * DP;
 
@@ -1520,10 +1521,12 @@ int fullcov_list_cap(int64_t n, int nb) {
 // component masks (16 bits each), the lists (one int per tile and (chain, block) slot) and their offsets
 size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t ntiles = (size_t)((n + FT - 1) / FT);
-  const size_t nb = (size_t)fullcov_blocks(n, c);
+  const size_t nb = (size_t)fullcov_blocks(n, c), nbg = (size_t)fullcov_blocks(n, c, true);
+  const size_t lists = (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
+  const size_t listsg = (size_t)c * nbg * ((size_t)fullcov_list_cap(n, (int)nbg) + kListOffs);
   const size_t ngroups = (ntiles + 63) / 64;
   return (ntiles + ngroups) * (DP + 1) + 2 * (size_t)c * k + ((size_t)c * (ntiles + ngroups) + 1) / 2 + 2 +
-         (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
+         (lists > listsg ? lists : listsg);
 }
 
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
@@ -1550,7 +1553,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   float* cst = blo + (size_t)c * k * DP;
   float* partials = cst + (size_t)c * k;
   const int64_t ntiles = (n + FT - 1) / FT;
-  const int nblk = fullcov_blocks(n, c), reps = fullcov_replicas(k), cap = fullcov_list_cap(n, nblk);
+  const int nblk = fullcov_blocks(n, c, grad != nullptr), reps = fullcov_replicas(k), cap = fullcov_list_cap(n, nblk);
   const size_t pstride = (size_t)c * ((size_t)k * (1 + DP + DP * DP) + 1);
   float* tstat = partials + (size_t)nblk * (1 + reps) * pstride;
   const int64_t ngroups = (ntiles + 63) / 64;
@@ -1564,7 +1567,7 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
   static const bool use_f32 = getenv("BVI_FULLCOV_F32") && atoi(getenv("BVI_FULLCOV_F32")) != 0;
-  const int nb = fullcov_blocks(n, c);
+  const int nb = fullcov_blocks(n, c, grad != nullptr);
   int nb_total = nb;
   dim3 grid(nb, c);
   if (use_f32) {
@@ -1590,10 +1593,11 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   } else {
     static const bool no_prune = getenv("BVI_FULLCOV_NO_PRUNE") && atoi(getenv("BVI_FULLCOV_NO_PRUNE")) != 0;
     const bool prune = k > 1 && ntiles > 0 && !no_prune;       // one component: nothing to leave out
-    hipLaunchKernelGGL(fullcov_tilestats, dim3(kStatBlocks), dim3(256), 0, s, Y, n, d, ntiles,
+    const int sblocks = (int)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > kStatBlocks ? kStatBlocks : ntiles / 4));
+    hipLaunchKernelGGL(fullcov_tilestats, dim3(sblocks), dim3(256), 0, s, Y, n, d, ntiles,
                        prune ? tstat : (float*)nullptr, psum, pmin, pmax);
-    hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(256), 0, s, (const double*)psum, (const float*)pmin,
-                       (const float*)pmax, kStatBlocks, n, d, center, cscale);
+    hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(1024), 0, s, (const double*)psum, (const float*)pmin,
+                       (const float*)pmax, sblocks, n, d, center, cscale);
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
                        bvec, blo, cst);
     BVI_HIP_CHECK_LAUNCH();
@@ -1601,10 +1605,10 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
       hipLaunchKernelGGL(fullcov_anorm, dim3(c * k), dim3(256), 0, s, theta, k, d, (const float*)center, (const float*)Ainv,
                          anorm, mudist);
       hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
-      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 256), c), dim3(256), 0, s, (const float*)gstat,
+      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 64), c), dim3(64), 0, s, (const float*)gstat,
                          ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
                          (const float*)mudist, (const float*)center, c, (const unsigned short*)nullptr, (int64_t)0, gmask);
-      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ntiles, 256), c), dim3(256), 0, s, (const float*)tstat,
+      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ntiles, 64), c), dim3(64), 0, s, (const float*)tstat,
                          ntiles, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
                          (const float*)mudist, (const float*)center, c, (const unsigned short*)gmask, ngroups, tmask);
       BVI_HIP_CHECK_LAUNCH();
