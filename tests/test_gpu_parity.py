@@ -702,6 +702,42 @@ def test_gmm_fullcov_tile_kinds(nat, ws, gpu_device, d, k, n, spread, pair_gap):
     assert np.array_equal(lp2.cpu().numpy()[:3], lp[:3]) and np.array_equal(g2.cpu().numpy()[:3], g[:3])
 
 
+def test_gmm_fullcov_random_shapes(nat, ws, gpu_device):
+    """Thirty random shapes (K 1 .. 16, D 1 .. 32, 1 .. 2500 rows, 1 .. 5 chains; separated, overlapping or coincident
+    components; rows as drawn or cluster by cluster) against the float64 oracle: whatever mix of tile kinds the masks
+    produce, the sums are the oracle's."""
+    from bayes_vi_amd.fused_target import cluster_row_order
+    rng = np.random.default_rng(20261112)
+    for trial in range(30):
+        k, d = int(rng.integers(1, 17)), int(rng.integers(1, 33))
+        n, c = int(rng.integers(1, 2501)), int(rng.integers(1, 6))
+        sep = float(rng.choice([0.0, 1.5, 4.0, 12.0]))
+        true_mu = rng.normal(size=(k, d)) * sep
+        comp = rng.integers(0, k, n)
+        Y = (true_mu[comp] + rng.normal(size=(n, d))).astype(np.float32)
+        w = (rng.dirichlet(np.ones(k) * 3, c) + 1e-3).astype(np.float32)
+        mu = (true_mu[None] + rng.normal(0, 0.2, (c, k, d))).astype(np.float32)
+        L = np.tril(rng.normal(size=(c, k, d, d)) * rng.choice([0.0, 0.05, 0.2]))
+        for i in range(d):
+            L[..., i, i] = rng.uniform(0.7, 1.5, (c, k))
+        L = L.astype(np.float32)
+        theta = np.concatenate([w, mu.reshape(c, -1), L.reshape(c, -1)], -1)
+        ref_lp, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+        ref_g = np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
+        Yd = dev(Y, gpu_device)
+        if trial % 2 == 0 and n >= 64:
+            Yd = Yd[cluster_row_order(Yd, k)].contiguous()
+        lp, g = nat.gmm_fullcov_logp_grad(Yd, dev(theta, gpu_device), k, ws)
+        what = 'trial %d: K=%d D=%d n=%d C=%d sep=%g' % (trial, k, d, n, c, sep)
+        try:
+            assert_logp_close(lp.cpu().numpy(), ref_lp)
+            assert_grad_close(g.cpu().numpy(), ref_g, term_scale=np.full_like(ref_g, 3.0 * n))
+        except AssertionError as e:
+            raise AssertionError(what + ': ' + str(e))
+        lpv, _ = nat.gmm_fullcov_logp_grad(Yd, dev(theta, gpu_device), k, ws, want_grad=False)
+        assert torch.equal(lpv, lp), what
+
+
 def test_logp_rebase_and_reference_level(nat, ws, gpu_device):
     """bvi_logp_rebase: the largest finite stored log-density becomes 0, the level takes it (split over the row
     shards), the absolute values come back, non-finite entries stay what they are; and a likelihood entry point
