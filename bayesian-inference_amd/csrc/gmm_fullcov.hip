@@ -255,6 +255,55 @@ __global__ __launch_bounds__(64) void fullcov_groupstats(const float* __restrict
   if (lane == 0) out[DP] = rs;
 }
 
+// The bounds of fullcov_bounds for the groups of 64 tiles, one (chain, component) per workgroup and one group per
+// lane (the groups are few: looping over the components per group would leave the chip empty):
+// gb[chain][group][k] = (upper, lower) bound of component k's log-density over the group's rows; anything
+// non-finite becomes (+inf, -inf), which keeps the component and never serves as the threshold.
+__global__ __launch_bounds__(64) void fullcov_group_bounds(const float* __restrict__ gstat, int64_t ngroups, int K,
+                                                           const float* __restrict__ Ainv, const float* __restrict__ bvec,
+                                                           const float* __restrict__ cst, const float* __restrict__ anorm,
+                                                           const float* __restrict__ center, float2* __restrict__ gb) {
+  const int c = blockIdx.y, k = blockIdx.z, lane = threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+  __shared__ __attribute__((aligned(16))) float As[DP * DP];
+  __shared__ float bs[DP];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<f32x4*>(&As[4 * (lane + 64 * q)]) =
+        *reinterpret_cast<const f32x4*>(Ainv + ((int64_t)c * K + k) * DP * DP + 4 * (lane + 64 * q));
+  if (lane < DP) bs[lane] = bvec[((int64_t)c * K + k) * DP + lane];
+  __syncthreads();
+  const bool tv = t < ngroups;
+  const float* ts = gstat + (tv ? t : 0) * (DP + 1);
+  float dm[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) dm[d] = ts[d] - center[d];
+  const float r = ts[DP];
+  float d2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    float sacc = -bs[i];
+#pragma unroll
+    for (int j4 = 0; j4 <= i; j4 += 4) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[i * DP + j4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j4 + e <= i) sacc = fmaf(a4[e], dm[j4 + e], sacc);
+    }
+    d2 = fmaf(sacc, sacc, d2);
+  }
+  const float dk = sqrtf(d2), slack = anorm[c * K + k] * r * 1.001f + 1e-3f;
+  const float lo = fmaxf(dk - slack, 0.f), hi = dk + slack;
+  const float ck = cst[c * K + k];
+  float ub = ck - 0.5f * lo * lo, lb = ck - 0.5f * hi * hi;
+  if (!(fabsf(ub) < INFINITY) || !(fabsf(lb) < INFINITY)) {
+    // a component of weight 0 (constant -inf) is out of reach everywhere; anything else that is not finite stays in
+    ub = ck > -INFINITY || ck != ck ? INFINITY : -INFINITY;
+    lb = -INFINITY;
+  }
+  if (tv) gb[((int64_t)c * ngroups + t) * K + k] = make_float2(ub, lb);
+}
+
 // Which components a sphere of rows (a tile, or a group of 64 tiles) can leave out.  For a row y in the sphere and
 // u_k(y) = A_k (y - mu_k):
 //   | |u_k(y)| - |u_k(m)| | <= |A_k|_2 |y - m| <= anorm_k r      (m, r: the sphere's centre and radius)
@@ -266,14 +315,14 @@ __global__ __launch_bounds__(64) void fullcov_groupstats(const float* __restrict
 //   1. without any product: |u_k(m)| <= anorm_k (|m - centre| + |mu_k - centre|) bounds lo_k from above and
 //      hi_j >= anorm_j r bounds the largest lower bound from above; if that already keeps every component (rows in
 //      no particular order: r is the size of the whole dataset) the sphere is done;
-//   2. the test itself, only for the components the sphere's group kept (`parent`, one mask per 64 spheres: with
-//      rows stored cluster by cluster most components are ruled out for 64 tiles at once).
+//   2. the test itself, only for the components the sphere's group of 64 kept (`parent`: the group's bounds from
+//      fullcov_group_bounds; with rows stored cluster by cluster most components are ruled out for 64 tiles at once).
 __global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K,
                                                       const float* __restrict__ Ainv, const float* __restrict__ bvec,
                                                       const float* __restrict__ cst, const float* __restrict__ anorm,
                                                       const float* __restrict__ mudist,
                                                       const float* __restrict__ center, int C,
-                                                      const unsigned short* __restrict__ parent, int64_t nparent,
+                                                      const float2* __restrict__ parent, int64_t nparent,
                                                       unsigned short* __restrict__ mask_out) {
   const int c = blockIdx.y, lane = threadIdx.x;
   const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -310,7 +359,16 @@ __global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ t
   unsigned sup = 0;
   if (__builtin_amdgcn_ballot_w64(tv && !keeps_all) != 0) {
     sup = full;
-    if (parent) sup = __builtin_amdgcn_readfirstlane((unsigned)parent[(int64_t)c * nparent + (t - lane) / 64]) & full;
+    if (parent) {                                       // the group's mask from its components' bounds
+      const float2* pb = parent + ((int64_t)c * nparent + (t - lane) / 64) * K;
+      float gbest = -INFINITY;
+      for (int k = 0; k < K; ++k) gbest = fmaxf(gbest, pb[k].y);
+      const float gth = gbest - 32.f - 1e-4f * fabsf(gbest);
+      sup = 0;
+      for (int k = 0; k < K; ++k)
+        if (!(pb[k].x < gth)) sup |= 1u << k;
+      sup = __builtin_amdgcn_readfirstlane(sup);
+    }
   }
   float best = -INFINITY;
   bool odd = false;                      // something is not finite: keep everything the parent kept
@@ -1525,7 +1583,8 @@ size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t lists = (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
   const size_t listsg = (size_t)c * nbg * ((size_t)fullcov_list_cap(n, (int)nbg) + kListOffs);
   const size_t ngroups = (ntiles + 63) / 64;
-  return (ntiles + ngroups) * (DP + 1) + 2 * (size_t)c * k + ((size_t)c * (ntiles + ngroups) + 1) / 2 + 2 +
+  return (ntiles + ngroups) * (DP + 1) + 2 * (size_t)c * k + 2 * (size_t)c * ngroups * k + 2 +
+         ((size_t)c * ntiles + 1) / 2 + 2 +
          (lists > listsg ? lists : listsg);
 }
 
@@ -1560,9 +1619,11 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   float* gstat = tstat + (size_t)ntiles * (DP + 1);
   float* anorm = gstat + (size_t)ngroups * (DP + 1);
   float* mudist = anorm + (size_t)c * k;
-  unsigned short* tmask = reinterpret_cast<unsigned short*>(mudist + (size_t)c * k);
-  unsigned short* gmask = tmask + (size_t)c * ntiles;
-  int* tlist = reinterpret_cast<int*>(mudist + (size_t)c * k + ((size_t)c * (ntiles + ngroups) + 1) / 2 + 2);
+  float* gb0 = mudist + (size_t)c * k;
+  gb0 += ((uintptr_t)gb0 & 7) ? 1 : 0;                 // float2 entries
+  float2* gbounds = reinterpret_cast<float2*>(gb0);
+  unsigned short* tmask = reinterpret_cast<unsigned short*>(gb0 + 2 * (size_t)c * ngroups * k);
+  int* tlist = reinterpret_cast<int*>(gb0 + 2 * (size_t)c * ngroups * k + ((size_t)c * ntiles + 1) / 2 + 2);
   int* toff = tlist + (size_t)c * nblk * cap;
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
@@ -1605,12 +1666,12 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
       hipLaunchKernelGGL(fullcov_anorm, dim3(c * k), dim3(256), 0, s, theta, k, d, (const float*)center, (const float*)Ainv,
                          anorm, mudist);
       hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
-      hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 64), c), dim3(64), 0, s, (const float*)gstat,
-                         ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
-                         (const float*)mudist, (const float*)center, c, (const unsigned short*)nullptr, (int64_t)0, gmask);
+      hipLaunchKernelGGL(fullcov_group_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 64), c, k), dim3(64), 0, s,
+                         (const float*)gstat, ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst,
+                         (const float*)anorm, (const float*)center, gbounds);
       hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ntiles, 64), c), dim3(64), 0, s, (const float*)tstat,
                          ntiles, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
-                         (const float*)mudist, (const float*)center, c, (const unsigned short*)gmask, ngroups, tmask);
+                         (const float*)mudist, (const float*)center, c, (const float2*)gbounds, ngroups, tmask);
       BVI_HIP_CHECK_LAUNCH();
     }
     const unsigned short* tmask_arg = prune ? tmask : nullptr;
