@@ -48,13 +48,18 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
   const float* mu = th + K + k * D;
   const float* L = th + K + K * D + k * D * D;
   __shared__ double A[DP][DP + 1];
-  for (int i = 0; i < DP; ++i) A[i][j] = 0.0;
+  __shared__ float Ls[DP][DP + 1];             // L staged once: the substitution below is one dependent chain per column
+  for (int i = 0; i < DP; ++i) {
+    A[i][j] = 0.0;
+    Ls[i][j] = (i < D && j < D) ? L[i * D + j] : 0.f;
+  }
+  __syncthreads();
   if (j < D) {
     // column j of L^-1 by forward substitution
     for (int i = j; i < D; ++i) {
       double s = (i == j) ? 1.0 : 0.0;
-      for (int m = j; m < i; ++m) s -= (double)L[i * D + m] * A[m][j];
-      A[i][j] = s / (double)L[i * D + i];
+      for (int m = j; m < i; ++m) s -= (double)Ls[i][m] * A[m][j];
+      A[i][j] = s / (double)Ls[i][i];
     }
   }
   __syncthreads();
@@ -70,7 +75,7 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
   if (j == 0) {
     double wsum = 0.0, ld = 0.0;
     for (int m = 0; m < K; ++m) wsum += (double)th[m];
-    for (int m = 0; m < D; ++m) ld += log((double)L[m * D + m]);
+    for (int m = 0; m < D; ++m) ld += log((double)Ls[m][m]);
     cst[c * K + k] = (float)(log((double)th[k]) - log(wsum) - ld - 0.5 * D * BVI_LN2PI_D);
   }
 }
