@@ -1064,60 +1064,23 @@ __global__ __launch_bounds__(1024) void f16_header_kernel(const float* __restric
   }
 }
 
-template <int D>
-__global__ void f16_pack_kernel(const float* __restrict__ X, const float* __restrict__ y, int64_t n, int dr,
-                                int64_t n_pad, unsigned char* __restrict__ packed) {
-  constexpr int TPR = D / 8;
-  const Header* hdr = reinterpret_cast<const Header*>(packed);
-  unsigned char* planes = packed + kHeader;
-  unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
-  const int64_t total = n_pad * TPR;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = idx / TPR;
-    const int scol = (int)(idx % TPR) * 8;
-    const bool ok = row < n;
-    float v[8];
-    if (ok && dr == D) {
-      const f32x4* p = reinterpret_cast<const f32x4*>(X + row * D + scol);
-      const f32x4 a = p[0], b = p[1];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
-    } else if (ok) {      // fewer features than plane columns: rows are not 16-B aligned, the rest is zero
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = scol + j < dr ? X[row * dr + scol + j] : 0.f;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    }
-    f16x8 fh;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)      // padding rows stay zero (not -shift)
-      fh[j] = ok ? (_Float16)plane_value(v[j], hdr->shift[scol + j], hdr->colscale[scol + j]) : (_Float16)0.f;
-    *reinterpret_cast<f16x8*>(planes + (row * D + scol) * 2) = fh;
-    if (scol == 0) *reinterpret_cast<float*>(yplane + row * 4) = ok ? y[row] : 0.f;
-  }
-}
-
 // ---- pack-time sums (once per dataset) -------------------------------------------------------------------------
 // With h the f16 plane (as numbers), x' = (x - shift) s the exact scaled entry and r = x' - h what the plane leaves
 // out, the finalize kernel needs, in double,
 //   X^T X = H^T H + A,   A = X^T X - H^T H = P + P^T + R^T R,   Bt = P,   P[f][g] = sum_i h_if r_ig,
 //   XR^T y = sum_i r_i y_i,   XR^T 1 = sum_i r_i
 // (all brought back to the columns' own units at the end: the scales are powers of two).  The three 64 x 64 products
-// run on v_mfma_f32_16x16x4_f32 -- h is an f16 number and r is rounded to f32 once (6e-8 of itself), so every
-// product of two operands is exact to f32 rounding -- as sums over ONE 64-row tile in f32, which each wave then adds
-// to its running totals in double: a tile sum carries ~1e-7 of its own size, independent from tile to tile, and
-// the totals over 10^5 tiles end up good to ~1e-9 of the sums of magnitudes -- far inside what the compensation
-// needs (its terms are 2^-12-sized corrections of sums that are themselves held to 1e-5).  The two vectors are
-// summed in double by the staging threads from the exact r.  Everything is added in a fixed order: the packed
-// dataset is bit-for-bit the same from run to run.  (The first version of these sums ran as 4 x 4 register tiles of
-// double-precision fma on the vector ALU, bound by its LDS reads: 24 ms of a 30 ms pack step at N = 10M, D = 64.)
-//
-// Workgroup = 4 waves with one role each over the staged tile: H^T H (upper tiles), R^T R (upper tiles), and the two
-// halves of P.  A[m = feature][k = row] and B[k = row][n = feature] of a 4-row step are the same LDS reads (lane l:
-// feature 16 t + (l & 15), row 4 step + (l >> 4)); D[m][n]: lane l, register i holds m = 4 (l >> 4) + i, n = l & 15.
+// run on the f16 matrix cores as sums over ONE 64-row tile in f32, which each wave then adds to its running totals
+// in double: a tile sum carries ~1e-7 of its own size, independent from tile to tile, and the totals over 10^5 tiles
+// end up good to ~1e-9 of the sums of magnitudes -- far inside what the compensation needs (its terms are
+// 2^-12-sized corrections of sums that are themselves held to 1e-5).  The two vectors are summed in double by the
+// staging threads from the exact r.  Everything is added in a fixed order: the packed dataset is bit-for-bit the
+// same from run to run.  (The first version of these sums ran as 4 x 4 register tiles of double-precision fma on the
+// vector ALU, bound by its LDS reads: 24 ms of a 30 ms pack step at N = 10M, D = 64; the second on
+// v_mfma_f32_16x16x4_f32 over f32 planes.)  D[m][n] of a product: lane l, register i holds m = 4 (l >> 4) + i,
+// n = l & 15.
 constexpr int kGramBlocks = 512;          // two to three resident per CU: one stages while another multiplies
+constexpr double kRScale = 2048.0;         // the remainder planes hold 2^11 r (see f16_pack_sums_kernel)
 constexpr int kSumStride = 3 * 64 * 64 + 128;     // per block: H^T H | R^T R | P | XR^T y | XR^T 1 (doubles)
 static_assert(kSumStride == 64 * 64 + kLowStride, "scratch layout");
 
@@ -1137,36 +1100,6 @@ constexpr int sums_gt(int role, int ntl, int t) {
 }
 constexpr int sums_tiles(int role, int ntl) { return role < 2 ? ntl * (ntl + 1) / 2 : ntl * ntl / 2; }
 
-// one staged 64-row tile for one role: 16 steps of 4 rows, tile sums in f32, added to the running totals in double
-template <int D, int ROLE, int NT, int SL>
-__device__ __forceinline__ void sums_tile(const float (*ht)[SL], const float (*rt)[SL], int ln, int g,
-                                          double (&accd)[NT][4]) {
-  constexpr int NTL = D / 16, NTW = sums_tiles(ROLE, NTL);
-  const float (*ma)[SL] = ROLE == 1 ? rt : ht;          // A side: h for H^T H and P, r for R^T R
-  const float (*mb)[SL] = ROLE == 0 ? ht : rt;          // B side: h for H^T H, r for R^T R and P
-  f32x4v accf[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) accf[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int step = 0; step < 16; ++step) {
-    const int row = 4 * step + g;
-    float fa[NTL], fb[NTL];
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-      fa[t] = ma[row][16 * t + ln];
-      fb[t] = ROLE < 2 ? fa[t] : mb[row][16 * t + ln];
-    }
-    static_for<NTW>([&](auto tc) {
-      constexpr int t = decltype(tc)::value;
-      accf[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sums_ft(ROLE, NTL, t)], fb[sums_gt(ROLE, NTL, t)], accf[t], 0, 0, 0);
-    });
-  }
-#pragma unroll
-  for (int t = 0; t < NTW; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accd[t][i] += (double)accf[t][i];
-}
-
 template <int D, int ROLE, int NT>
 __device__ __forceinline__ void sums_store(double* __restrict__ out, int ln, int g, const double (&accd)[NT][4]) {
   constexpr int NTL = D / 16, NTW = sums_tiles(ROLE, NTL);
@@ -1179,54 +1112,164 @@ __device__ __forceinline__ void sums_store(double* __restrict__ out, int ln, int
   });
 }
 
+// The plane and the sums in one pass over X.  Workgroup = 256 threads over 64-row tiles: every thread turns one or two
+// 8-column pieces of a row into the plane's f16 values h (written to the packed buffer), the remainder r = x' - h in
+// double and the two f16 pieces r1 + r2 of 2^11 r (r to 2^-22 of itself), and
+// stores h, r1, r2 as three swizzled f16 images in LDS; the four waves then take one role each -- H^T H (upper
+// tiles), R1^T R1 (upper tiles: R^T R to 2^-10 of itself, a term 2^-24 the size of H^T H), and the two halves of
+// P = H^T (R1 + R2) -- as v_mfma_f32_16x16x32_f16 products whose operands are both transposed reads of those images
+// (ds_read_tr16_b64: lane = feature, eight rows of a 32-row step each, the same row order on both sides).  Every
+// product of two f16 numbers is exact in f32; a tile's 64 addends are summed in the f32 accumulator and the tile
+// sums added to running totals in double, in a fixed order.  (The previous version multiplied f32 planes with
+// v_mfma_f32_16x16x4_f32, a sixteenth of the rate, in a pass of its own: 4.4 + 1.3 ms at N = 10M, D = 64.)
 template <int D>
-__global__ __launch_bounds__(256) void f16_sums_kernel(const float* __restrict__ X, const float* __restrict__ y,
-                                                       int64_t n, int dr, const Header* __restrict__ hdr,
-                                                       double* __restrict__ part) {
+__global__ __launch_bounds__(256) void f16_pack_sums_kernel(const float* __restrict__ X, const float* __restrict__ y,
+                                                            int64_t n, int dr, int64_t n_pad,
+                                                            unsigned char* __restrict__ packed,
+                                                            double* __restrict__ part) {
   constexpr int NTL = D / 16;                    // feature tiles per side
-  constexpr int SL = D + 16;                     // LDS row stride: the four rows of a step land on distinct banks
+  constexpr int TPR = D / 8;                     // 8-column pieces per row
+  constexpr int PER = 64 * TPR / 256;            // pieces per thread and tile
+  constexpr int SA = 2 * D;                      // LDS row stride in bytes (16-B chunks XOR-swizzled by row)
   constexpr int NT = sums_tiles(0, NTL) > sums_tiles(2, NTL) ? sums_tiles(0, NTL) : sums_tiles(2, NTL);
-  constexpr int RL = 256 / D;                    // row lanes of the staging
-  __shared__ float ht[64][SL], rt[64][SL];
-  __shared__ double colred[2][256];
+  static_assert(PER >= 1 && 256 % TPR == 0, "staging shape");
+  __shared__ __attribute__((aligned(16))) unsigned char img[3][64 * SA];   // h | r1 | r2
+  __shared__ double colred[2][256][8];
+  const Header* hdr = reinterpret_cast<const Header*>(packed);
+  unsigned char* planes = packed + kHeader;
+  unsigned char* yplane = planes + (int64_t)n_pad * D * 2;
   const int tid = threadIdx.x, lane = tid & 63, ln = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = tid % D, rl = tid / D;
-  const bool cin = col < dr;
-  const float shf = cin ? hdr->shift[col] : 0.f, csf = cin ? hdr->colscale[col] : 0.f;
-  double vy = 0.0, v1 = 0.0;
+  auto swz = [](int row) { return D == 64 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
+  const int scol = (tid % TPR) * 8;              // this thread's columns (the same for all its pieces)
+  float shf[8], csf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool cin = scol + j < dr;
+    shf[j] = cin ? hdr->shift[scol + j] : 0.f;
+    csf[j] = cin ? hdr->colscale[scol + j] : 0.f;
+  }
+  double vy[8], v1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { vy[j] = 0.0; v1[j] = 0.0; }
   double accd[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) accd[t][i] = 0.0;
+  // transposed fragment of feature tile ft, 16-row half: lane (ln, g) -> row 4 g + (ln >> 2) of the half
+  int offX[NTL];
+#pragma unroll
+  for (int ft = 0; ft < NTL; ++ft) {
+    const int trow = 4 * g + (ln >> 2);          // swz(trow + 16) == swz(trow)
+    offX[ft] = trow * SA + (((2 * ft + ((ln & 3) >> 1)) ^ swz(trow)) << 4) + 8 * (ln & 1);
+  }
+  auto frag = [&](int plane, int step, int ft) {
+    const unsigned char* base = img[plane] + 32 * step * SA + offX[ft];
+    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 16 * SA));
+    return __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
 
-  const int64_t ntile = (n + 63) / 64;
+  const int64_t ntile = n_pad / 64;
+  // raw rows of a tile, one tile ahead: the loads of tile t + 1 are in flight while the waves multiply tile t
+  float v[PER][8], yv[PER];
+  auto load_tile = [&](int64_t t0) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int64_t row = t0 * 64 + (tid + e * 256) / TPR;
+      const bool ok = t0 < ntile && row < n;
+      if (ok && dr == D) {
+        const f32x4v* p = reinterpret_cast<const f32x4v*>(X + row * D + scol);
+        const f32x4v a = p[0], b = p[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[e][j] = a[j]; v[e][4 + j] = b[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[e][j] = (ok && scol + j < dr) ? X[row * dr + scol + j] : 0.f;
+      }
+      yv[e] = ok ? y[row] : 0.f;
+    }
+  };
+  load_tile(blockIdx.x);
   for (int64_t t0 = blockIdx.x; t0 < ntile; t0 += gridDim.x) {
     __syncthreads();                             // the previous tile's fragments have been read
-#pragma unroll 4
-    for (int r = rl; r < 64; r += RL) {
-      const int64_t row = t0 * 64 + r;
-      const bool in = cin && row < n;
-      const float v = in ? X[row * dr + col] : 0.f;
-      // the pack kernel's rounding for h; x' exact in double (the float rounding of x - shift is part of what the
-      // plane leaves out)
-      const double xd = in ? ((double)v - (double)shf) * (double)csf : 0.0;
-      const float hv = in ? (float)(_Float16)plane_value(v, shf, csf) : 0.f;
-      const double rd = xd - (double)hv;
-      ht[r][col] = hv;
-      rt[r][col] = (float)rd;
-      if (in) {
-        vy = fma(rd, (double)y[row], vy);
-        v1 += rd;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int idx = tid + e * 256;
+      const int srow = idx / TPR, ch = idx % TPR;
+      const int64_t row = t0 * 64 + srow;
+      const bool ok = row < n;
+      f16x8 fh, f1, f2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool in = ok && scol + j < dr;
+        // x' = (x - shift) s exactly, in f32 pieces: x - shift = d + err (two-sum), s is a power of two, so d s is
+        // the f32 value plane_value() rounds to f16 and the part the plane leaves out is (d s - h) + err s, both
+        // terms exact in f32; their f32 sum r is good to 2^-24 of itself.  Padding rows and columns stay zero.
+        const float nsh = -shf[j];
+        const float dlt = v[e][j] + nsh;
+        const float bb = dlt - v[e][j];
+        const float err = (v[e][j] - (dlt - bb)) + (nsh - bb);
+        const float xs = dlt * csf[j];
+        const _Float16 h = in ? (_Float16)xs : (_Float16)0.f;
+        const float r = in ? (xs - (float)h) + err * csf[j] : 0.f;
+        // the pieces of r are taken from 2^11 r: r is at most half a unit in the last place of h, and unscaled its
+        // second piece would fall among f16's subnormals (2^-24 apart) and lose what it is there to keep
+        const float rs = r * (float)kRScale;
+        const _Float16 r1 = (_Float16)rs;
+        fh[j] = h;
+        f1[j] = r1;
+        f2[j] = (_Float16)(rs - (float)r1);
+        vy[j] += (double)(r * yv[e]);
+        v1[j] += (double)r;
       }
+      *reinterpret_cast<f16x8*>(planes + (row * D + scol) * 2) = fh;
+      if (ch == 0) *reinterpret_cast<float*>(yplane + row * 4) = yv[e];
+      const int off = srow * SA + ((ch ^ swz(srow)) << 4);
+      *reinterpret_cast<f16x8*>(img[0] + off) = fh;
+      *reinterpret_cast<f16x8*>(img[1] + off) = f1;
+      *reinterpret_cast<f16x8*>(img[2] + off) = f2;
     }
+    load_tile(t0 + gridDim.x);
     __syncthreads();
     // one role per wave; the branches are wave-uniform and every wave comes back to the loop's two barriers
-    if (wave == 0) sums_tile<D, 0, NT, SL>(ht, rt, ln, g, accd);
-    else if (wave == 1) sums_tile<D, 1, NT, SL>(ht, rt, ln, g, accd);
-    else if (wave == 2) sums_tile<D, 2, NT, SL>(ht, rt, ln, g, accd);
-    else sums_tile<D, 3, NT, SL>(ht, rt, ln, g, accd);
+    auto role_tile = [&](auto role_c) {
+      constexpr int ROLE = decltype(role_c)::value;
+      constexpr int NTW = sums_tiles(ROLE, NTL);
+      constexpr double unscale = ROLE == 0 ? 1.0 : ROLE == 1 ? 1.0 / (kRScale * kRScale) : 1.0 / kRScale;
+      f32x4v accf[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) accf[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int step = 0; step < 2; ++step) {
+        f16x8 fa[NTL], fb[NTL], fc[NTL];         // A side; B side (and its second piece for P)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          if (ROLE == 0) { fa[t] = frag(0, step, t); fb[t] = fa[t]; }
+          else if (ROLE == 1) { fa[t] = frag(1, step, t); fb[t] = fa[t]; }
+          else {
+            if (t / (NTL / 2) == ROLE - 2) fa[t] = frag(0, step, t);
+            fb[t] = frag(1, step, t);
+            fc[t] = frag(2, step, t);
+          }
+        }
+        static_for<NTW>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int ft = sums_ft(ROLE, NTL, t), gt = sums_gt(ROLE, NTL, t);
+          accf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ft], fb[gt], accf[t], 0, 0, 0);
+          if constexpr (ROLE >= 2) accf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ft], fc[gt], accf[t], 0, 0, 0);
+        });
+      }
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accd[t][i] = fma((double)accf[t][i], unscale, accd[t][i]);
+    };
+    if (wave == 0) role_tile(std::integral_constant<int, 0>{});
+    else if (wave == 1) role_tile(std::integral_constant<int, 1>{});
+    else if (wave == 2) role_tile(std::integral_constant<int, 2>{});
+    else role_tile(std::integral_constant<int, 3>{});
   }
 
   double* out = part + (int64_t)blockIdx.x * kSumStride;
@@ -1234,18 +1277,21 @@ __global__ __launch_bounds__(256) void f16_sums_kernel(const float* __restrict__
   else if (wave == 1) sums_store<D, 1, NT>(out, ln, g, accd);
   else if (wave == 2) sums_store<D, 2, NT>(out, ln, g, accd);
   else sums_store<D, 3, NT>(out, ln, g, accd);
-  // the two vectors: the RL threads of a column add up in a fixed order
-  colred[0][tid] = vy;
-  colred[1][tid] = v1;
+  // the two vectors: the threads that share a column piece add up in a fixed order
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { colred[0][tid][j] = vy[j]; colred[1][tid][j] = v1[j]; }
   __syncthreads();
-  if (rl == 0) {
-    double sy = vy, s1 = v1;
-    for (int q = 1; q < RL; ++q) {
-      sy += colred[0][q * D + col];
-      s1 += colred[1][q * D + col];
+  if (tid < TPR) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double sy = 0.0, s1 = 0.0;
+      for (int q = tid; q < 256; q += TPR) {
+        sy += colred[0][q][j];
+        s1 += colred[1][q][j];
+      }
+      out[3 * 4096 + scol + j] = sy;
+      out[3 * 4096 + 64 + scol + j] = s1;
     }
-    out[3 * 4096 + col] = sy;
-    out[3 * 4096 + 64 + col] = s1;
   }
 }
 
@@ -1255,18 +1301,26 @@ __device__ __forceinline__ double iq0(const Header* hdr, int q) {
 }
 
 // stage 2: fixed-order sums over the blocks, assembled into X^T X (gram) and A | Bt | XR^T y | XR^T 1 (low) in the
-// columns' own units; entries beyond the model's features are zero.  One thread per matrix entry (p, q).
-__global__ void f16_sums_final(const double* __restrict__ part, int nblk, int D, const Header* __restrict__ hdr,
-                               double* __restrict__ gram, double* __restrict__ low) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 64 * 64) return;
+// columns' own units; entries beyond the model's features are zero.  Eight lanes per matrix entry (p, q): lane s adds
+// blocks s, s + 8, ... in order, then the eight are added in a fixed butterfly.
+constexpr int kFinalSplit = 8;
+__device__ __forceinline__ double split_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < kFinalSplit; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__global__ __launch_bounds__(256) void f16_sums_final(const double* __restrict__ part, int nblk, int D,
+                                                      const Header* __restrict__ hdr, double* __restrict__ gram,
+                                                      double* __restrict__ low) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = t / kFinalSplit, sub = t % kFinalSplit;      // the grid covers 64 * 64 entries exactly
   const int p = e >> 6, q = e & 63;
   const bool in = p < D && q < D;
   double hh = 0.0, rr = 0.0, pq = 0.0, qp = 0.0;
   if (in) {
     // the symmetric products hold their upper tiles only
     const int su = (p >> 4) <= (q >> 4) ? p * 64 + q : q * 64 + p;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = sub; b < nblk; b += kFinalSplit) {
       const double* o = part + (int64_t)b * kSumStride;
       hh += o[su];
       rr += o[4096 + su];
@@ -1274,18 +1328,19 @@ __global__ void f16_sums_final(const double* __restrict__ part, int nblk, int D,
       qp += o[8192 + q * 64 + p];
     }
   }
+  hh = split_sum(hh); rr = split_sum(rr); pq = split_sum(pq); qp = split_sum(qp);
+  double s = 0.0;                                  // rows 0, 1 of the grid also carry the two vectors
+  if (p < 2 && q < D)
+    for (int b = sub; b < nblk; b += kFinalSplit) s += part[(int64_t)b * kSumStride + 3 * 4096 + 64 * p + q];
+  s = split_sum(s);
+  if (sub != 0) return;
   const float cp = in ? hdr->colscale[p] : 0.f, cq = in ? hdr->colscale[q] : 0.f;
   const double ip = cp > 0.f ? 1.0 / (double)cp : 0.0, iq = cq > 0.f ? 1.0 / (double)cq : 0.0;
   const double a = (pq + qp) + rr;
   gram[e] = (hh + a) * ip * iq;
   low[e] = a * ip * iq;
   low[4096 + e] = pq * ip * iq;
-  if (p < 2) {                                   // rows 0, 1 of the grid also carry the two vectors
-    double s = 0.0;
-    if (q < D)
-      for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * kSumStride + 3 * 4096 + 64 * p + q];
-    low[8192 + 64 * p + q] = s * (q < D ? iq0(hdr, q) : 0.0);
-  }
+  if (p < 2) low[8192 + 64 * p + q] = s * (q < D ? iq0(hdr, q) : 0.0);
 }
 
 // finalize, one workgroup of kFinGroups waves per chain: fixed-order reduction over row blocks in double (a wave
@@ -1503,8 +1558,8 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
                        (const float*)((const Header*)packed)->shift, pmax, psum);
     hipLaunchKernelGGL((f16_header_kernel<64, true>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
                        (const double*)psum, kStatBlocks, n, (Header*)packed);
-    hipLaunchKernelGGL(f16_pack_kernel<64>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
-    hipLaunchKernelGGL(f16_sums_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, gpart);
+    hipLaunchKernelGGL(f16_pack_sums_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed,
+                       gpart);
   } else {
     hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
                        pmax, psum);
@@ -1514,10 +1569,10 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
                        (const float*)((const Header*)packed)->shift, pmax, psum);
     hipLaunchKernelGGL((f16_header_kernel<32, true>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
                        (const double*)psum, kStatBlocks, n, (Header*)packed);
-    hipLaunchKernelGGL(f16_pack_kernel<32>, dim3(blocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed);
-    hipLaunchKernelGGL(f16_sums_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, (const Header*)packed, gpart);
+    hipLaunchKernelGGL(f16_pack_sums_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed,
+                       gpart);
   }
-  hipLaunchKernelGGL(f16_sums_final, dim3(16), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp,
+  hipLaunchKernelGGL(f16_sums_final, dim3(64 * 64 * kFinalSplit / 256), dim3(256), 0, s, (const double*)gpart, kGramBlocks, dp,
                      (const Header*)packed, gram, low);
   BVI_HIP_CHECK_LAUNCH();
   return BVI_OK;
