@@ -21,7 +21,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET, PRIOR_WISHART_TRIL 
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 110     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 111     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -78,6 +78,8 @@ def lib():
         l.bvi_normal_iid_logp_grad_noalloc.restype = i32
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_cluster_rows_scratch_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]
+        l.bvi_cluster_rows.argtypes = [vp, i64, i32, i32, vp, vp, vp, sz, vp]
         l.bvi_mvn_tril_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_logp_rebase.argtypes = [i32, vp, i32, vp, vp, vp]
         l.bvi_logp_rebase_shard.argtypes = [i32, vp, ctypes.c_double, vp, vp, vp]
@@ -308,6 +310,25 @@ def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True, logp_ref=N
                                           _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()),
           'bvi_gmm_fullcov_logp_grad')
     return logp, grad
+
+
+CLUSTER_MAX_CENTRES = 128
+
+
+def cluster_rows(Y, n_centres, want_order=False):
+    """bvi_cluster_rows: a copy of Y[n, d] with rows that lie close together stored next to each other (and, if asked
+    for, order[n] with copy[i] = Y[order[i]])."""
+    _check_f32_cuda(Y)
+    n, d = Y.shape
+    m = int(max(1, min(CLUSTER_MAX_CENTRES, n_centres)))
+    out = ctypes.c_size_t(0)
+    check(lib().bvi_cluster_rows_scratch_bytes(n, d, m, ctypes.byref(out)), 'bvi_cluster_rows_scratch_bytes')
+    scratch = torch.empty(max(int(out.value), 16), dtype=torch.uint8, device=Y.device)
+    Yout = torch.empty_like(Y)
+    order = torch.empty(n, dtype=torch.int64, device=Y.device) if want_order else None
+    check(lib().bvi_cluster_rows(_ptr(Y), n, d, m, _ptr(Yout), _ptr(order), _ptr(scratch), scratch.numel(),
+                                 _stream()), 'bvi_cluster_rows')
+    return (Yout, order) if want_order else Yout
 
 
 def mvn_tril_logp_grad(Y, theta, parameterisation, ws: Workspace, want_grad=True, logp_ref=None):

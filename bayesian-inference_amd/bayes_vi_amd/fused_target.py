@@ -223,37 +223,19 @@ class GaussianMixture1D(FusedLogLikelihood):
                 _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf), buf.numel(), _native._stream())
 
 
-def cluster_row_order(Y, k, seed=0):
-    """A permutation of the rows of Y[N, D] that puts rows lying close together next to each other: a few rounds of
-    Lloyd's algorithm on 4 k centres (started from rows drawn with a fixed seed), rows ordered by the centre they
-    end up with.  The rows of a likelihood sum are exchangeable, so their order in memory is the layout's to choose;
-    the full-covariance mixture kernel leaves a component out of its raw-sums phase for every 32-row block in
-    which no row gives it a responsibility above 2^-40, which is most blocks once neighbouring rows belong to the
-    same few components.  Cost: a handful of [N, 4 k] distance passes, once per dataset."""
-    n, d = Y.shape
-    m = int(min(n, max(16, min(256, 4 * int(k)))))
-    if n <= m:
-        return torch.arange(n, device=Y.device)
-    g = torch.Generator(device=Y.device); g.manual_seed(seed)
-    cent = Y[torch.randint(0, n, (m,), generator=g, device=Y.device)].double()
-    step = 1 << 18
-    assign = torch.empty(n, dtype=torch.long, device=Y.device)
-    for it in range(3):
-        c32 = cent.float(); cn = (c32 * c32).sum(-1)
-        for s0 in range(0, n, step):
-            y = Y[s0:s0 + step]
-            assign[s0:s0 + step] = (cn[None, :] - 2.0 * (y @ c32.T)).argmin(-1)
-        if it == 2:
-            break
-        # centre sums as one-hot^T @ rows per chunk (a scatter-add into 4 k targets would serialise on its atomics)
-        cnt = torch.zeros(m, dtype=torch.float64, device=Y.device)
-        tot = torch.zeros(m, d, dtype=torch.float64, device=Y.device)
-        for s0 in range(0, n, step):
-            hot = torch.nn.functional.one_hot(assign[s0:s0 + step], m).to(torch.float32)
-            tot += (hot.T @ Y[s0:s0 + step]).double()
-            cnt += hot.sum(0).double()
-        cent = torch.where(cnt[:, None] > 0, tot / cnt.clamp_min(1.0)[:, None], cent)
-    return torch.sort(assign, stable=True).indices
+def cluster_centres(k):
+    """Centres the row ordering of a k-component mixture works with: 4 k, at least 16."""
+    return int(min(_native.CLUSTER_MAX_CENTRES, max(16, 4 * int(k))))
+
+
+def cluster_row_order(Y, k):
+    """A permutation of the rows of Y[N, D] that puts rows lying close together next to each other
+    (`bvi_cluster_rows`: Lloyd's algorithm on 4 k centres started from rows at a fixed stride, rows ordered by the
+    centre they end up with, reproducible bit for bit).  The rows of a likelihood sum are exchangeable, so their order
+    in memory is the layout's to choose; the full-covariance mixture kernels leave a component out of every 64-row
+    tile it cannot reach, which is most tiles once neighbouring rows belong to the same few components.  Cost: a
+    handful of [N, 4 k] distance passes, once per dataset."""
+    return _native.cluster_rows(Y.to(torch.float32).contiguous(), cluster_centres(k), want_order=True)[1]
 
 
 class GaussianMixtureFullCov(FusedLogLikelihood):
@@ -267,7 +249,7 @@ class GaussianMixtureFullCov(FusedLogLikelihood):
         super().__init__(Y.device, group)
         self.Y = Y.to(torch.float32).contiguous()
         if cluster_rows and self.Y.shape[0] >= 4096:
-            self.Y = self.Y[cluster_row_order(self.Y, k)].contiguous()
+            self.Y = _native.cluster_rows(self.Y, cluster_centres(k))
         self.n, self.d = self.Y.shape
         self.k = int(k)
         self.n_params = self.k * (1 + self.d + self.d * self.d)

@@ -139,6 +139,21 @@ int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const flo
                                 logp_ref);
 }
 
+int bvi_cluster_rows_scratch_bytes(int64_t n, int d, int n_centres, size_t* out_bytes) {
+  if (!out_bytes || n < 0) return BVI_ERR_ARG;
+  if (d < 1 || d > 32 || n_centres < 1 || n_centres > BVI_CLUSTER_MAX_CENTRES) return BVI_ERR_UNSUPPORTED;
+  *out_bytes = bvi_ws_cluster_rows(n, d, n_centres);
+  return BVI_OK;
+}
+
+int bvi_cluster_rows(const float* Y, int64_t n, int d, int n_centres, float* Y_out, int64_t* order, void* ws,
+                     size_t ws_bytes, void* stream) {
+  if (((!Y || !Y_out) && n > 0) || n < 0 || Y == Y_out) return BVI_ERR_ARG;
+  if (d < 1 || d > 32 || n_centres < 1 || n_centres > BVI_CLUSTER_MAX_CENTRES) return BVI_ERR_UNSUPPORTED;
+  if (n > 0 && (!ws || ws_bytes < bvi_ws_cluster_rows(n, d, n_centres))) return BVI_ERR_WORKSPACE;
+  return bvi_launch_cluster_rows(Y, n, d, n_centres, Y_out, order, ws, (hipStream_t)stream);
+}
+
 int bvi_mvn_tril_logp_grad(const float* Y, int64_t n, int d, int parameterisation, const float* theta, int n_chains,
                            float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
                            void* stream) {

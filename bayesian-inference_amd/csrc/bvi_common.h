@@ -57,6 +57,10 @@ int bvi_launch_mvn_tril(const float* Y, int64_t n, int d, int mode, const float*
                         float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 size_t bvi_ws_mvn_tril(int64_t n, int c, int d);
 
+size_t bvi_ws_cluster_rows(int64_t n, int d, int m);
+int bvi_launch_cluster_rows(const float* Y, int64_t n, int d, int m, float* Yout, int64_t* order, void* ws,
+                            hipStream_t s);
+
 size_t bvi_linreg_f16_packed_size(int64_t n, int d);
 size_t bvi_linreg_f16_pack_scratch(int d);
 int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d, void* packed, void* scratch,

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 110
+#define BVI_VERSION 111
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -229,6 +229,19 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
 int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
                               float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
                               void* stream);
+
+/* One-time row order for bvi_gmm_fullcov_logp_grad: Y_out[n,d] = the rows of Y[n,d] stored so that rows lying close
+ * together are neighbours (Lloyd's algorithm on n_centres <= BVI_CLUSTER_MAX_CENTRES centres started from rows at a
+ * fixed stride, two updates, then a stable counting sort by nearest centre; a few n_centres-by-d distance passes over
+ * the rows).  order (optional, int64[n]): order[i] = the row of Y that Y_out's row i is.  The result is the same bit
+ * for bit on every run.  d <= 32; Y_out must not alias Y; rows with a non-finite entry are kept (with centre 0).
+ * 4 k centres (at least 16) is what the shipped host layer asks for a k-component mixture.
+ * No counterpart in the reference: the rows of a likelihood sum are exchangeable (the reference reduces them with
+ * tf.reduce_sum, bayes_vi/model/model.py:17-21), so the order in memory is this library's to choose. */
+#define BVI_CLUSTER_MAX_CENTRES 128
+int bvi_cluster_rows_scratch_bytes(int64_t n, int d, int n_centres, size_t* out_bytes);
+int bvi_cluster_rows(const float* Y, int64_t n, int d, int n_centres, float* Y_out, int64_t* order, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* Single multivariate normal: Y[n,d] row-major, theta[C, d + d*d] = (loc[d], M[d][d] row-major, entries above the
  * diagonal ignored) -> logp[C], grad[C, same layout] (gradient of M lower triangular).  `parameterisation` says

@@ -621,6 +621,36 @@ def test_gmm_fullcov(nat, ws, gpu_device, d, k, c, n):
     np.testing.assert_array_equal(lp2.cpu().numpy(), lp.cpu().numpy())
 
 
+@pytest.mark.parametrize('n,d,m', [(50000, 32, 64), (12345, 5, 16), (4097, 1, 128), (100, 7, 128), (1, 3, 16),
+                                   (300001, 16, 40)])
+def test_cluster_rows_is_a_stable_reproducible_grouping(nat, gpu_device, n, d, m):
+    """bvi_cluster_rows: the output holds every row exactly once (order is a permutation and Y_out = Y[order]), rows of
+    one group keep their original order (stable), two runs agree bit for bit, a row with a non-finite entry is kept,
+    and on well-separated clusters nearly every pair of neighbouring rows comes from the same cluster."""
+    rng = np.random.default_rng(n + 7 * d + m)
+    kc = 6
+    centre = rng.integers(-30, 31, (kc, d)).astype(np.float32) * 3.0
+    comp = rng.integers(0, kc, n)
+    Y = centre[comp] + rng.normal(size=(n, d)).astype(np.float32)
+    if n > 50:
+        Y[17, 0] = np.nan
+        Y[41, d - 1] = np.inf
+    Yd = dev(Y, gpu_device)
+    out, order = nat.cluster_rows(Yd, m, want_order=True)
+    out2, order2 = nat.cluster_rows(Yd, m, want_order=True)
+    assert torch.equal(order, order2) and torch.equal(out.view(torch.int32), out2.view(torch.int32))
+    assert torch.equal(torch.sort(order).values, torch.arange(n, device=gpu_device))
+    assert torch.equal(out.view(torch.int32), Yd[order].view(torch.int32))
+    o = order.cpu().numpy()
+    # groups are runs of increasing original index: at most m of them (fewer centres than rows: every row its own)
+    runs = 1 + int((np.diff(o) < 0).sum())
+    assert runs <= min(m, n)
+    if n >= 4096 and d >= 5:
+        changes = int((comp[o][1:] != comp[o][:-1]).sum())
+        assert changes <= 2 * m + 4, changes              # as drawn: ~ n (1 - 1 / kc)
+    assert nat.cluster_rows(Yd, m).shape == Yd.shape
+
+
 @pytest.mark.parametrize('d,k', [(8, 6), (32, 16)])
 def test_gmm_fullcov_rows_stored_cluster_by_cluster(nat, ws, gpu_device, d, k):
     """Well-separated components, the rows once as drawn and once in the order the host layer stores them

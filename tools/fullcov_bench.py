@@ -15,10 +15,10 @@ Y = mu[comp] + torch.randn(n, d, generator=g, device=dev)
 L = torch.tril(torch.randn(c, k, d, d, generator=g, device=dev) * 0.05)
 L = L + torch.diag_embed(1.0 + 0.1 * torch.rand(c, k, d, generator=g, device=dev))
 if '--clustered' in sys.argv:      # the order the host layer stores the rows in (GaussianMixtureFullCov)
-    from bayes_vi_amd.fused_target import cluster_row_order
+    from bayes_vi_amd.fused_target import cluster_centres
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    cluster_row_order(Y[:100000], k); torch.cuda.synchronize()          # loads the torch kernels it uses
-    e0.record(); Y = Y[cluster_row_order(Y, k)].contiguous(); e1.record(); torch.cuda.synchronize()
+    nat.cluster_rows(Y[:100000].contiguous(), cluster_centres(k)); torch.cuda.synchronize()          # loads the kernels
+    e0.record(); Y = nat.cluster_rows(Y, cluster_centres(k)); e1.record(); torch.cuda.synchronize()
     print('rows stored cluster by cluster (once per dataset): %.1f ms' % e0.elapsed_time(e1))
 w = torch.rand(c, k, generator=g, device=dev) + 0.5
 th = torch.cat([w, (mu[None] + 0.1 * torch.randn(c, k, d, generator=g, device=dev)).reshape(c, -1), L.reshape(c, -1)], -1).contiguous()
