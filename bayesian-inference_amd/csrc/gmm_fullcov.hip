@@ -743,7 +743,8 @@ __host__ __device__ __forceinline__ int fullcov_replicas(int K) { return K <= 1 
 // components.  One wave per (chain, block), 64 tiles per step, positions from ballots.
 constexpr int kLists = 2 * FW + 1, kListOffs = kLists + 2;   // starts, end, and the mode of the last list
 __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __restrict__ tmask, int64_t ntiles, int K,
-                                                        int cap, int* __restrict__ tlist, int* __restrict__ toff) {
+                                                        int cap, int* __restrict__ tlist, int* __restrict__ toff,
+                                                        int* __restrict__ any_single) {
   const int c = blockIdx.y, b = blockIdx.x, nb = gridDim.x, lane = threadIdx.x;
   const int R = fullcov_replicas(K), K8 = FW / R;
   const unsigned kmask = (1u << K) - 1u;
@@ -782,6 +783,7 @@ __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __
     for (int j = 0; j < kLists; ++j) so[j] = start[j];
     so[kLists] = run;
     so[kLists + 1] = (tmask != nullptr && saved * 8 >= K * count[kLists - 1] && saved > 0) ? 1 : 0;
+    if (start[kLists - 1] > 0) *any_single = 1;       // some tile goes to fullcov_single_kernel: it needs the planes
   }
   saved = 0;
   for (int i0 = 0; i0 < cnt_tiles; i0 += 64) {
@@ -1229,6 +1231,44 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
 }
 
 
+// The rows as fullcov_single_kernel multiplies them: (y - centre) scale in two f16 pieces, [tile rows][DP] each, rows
+// past the end and columns past D zero.  The split does not depend on the chain, and in that kernel -- one component,
+// no log-sum-exp -- it was a third of all vector instructions when every (chain, tile) redid it; one pass per call
+// (skipped when no tile is on a single-component list) does it once.
+__global__ __launch_bounds__(256) void fullcov_planes(const float* __restrict__ Y, int64_t n, int D, int64_t ntiles,
+                                                      const float* __restrict__ center, const float* __restrict__ cscale,
+                                                      const int* __restrict__ any_single,
+                                                      unsigned char* __restrict__ phi, unsigned char* __restrict__ plo) {
+  if (*any_single == 0) return;
+  const int g = threadIdx.x & 3;
+  float cm[8], cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { cm[e] = center[8 * g + e]; cs[e] = cscale[8 * g + e]; }
+  const bool vec_ok = D == DP && (((uintptr_t)Y & 15) == 0);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  for (int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2); row < ntiles * FT; row += (int64_t)gridDim.x * 64) {
+    float y[8];
+    if (vec_ok && row < n) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Y + row * DP + 8 * g);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Y + row * DP + 8 * g + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] = a[e]; y[4 + e] = b[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool in = row < n && 8 * g + e < D;
+        const float v = Y[in ? row * D + 8 * g + e : 0];       // (a tile exists, so Y[0] does)
+        y[e] = in ? v : cm[e];
+      }
+    }
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) fc_split_pair((y[e] - cm[e]) * cs[e], (y[e + 1] - cm[e + 1]) * cs[e + 1], hw[e >> 1], lw[e >> 1]);
+    *reinterpret_cast<u32x4*>(phi + row * 64 + 16 * g) = (u32x4){hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<u32x4*>(plo + row * 64 + 16 * g) = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+  }
+}
+
 // The tiles only ONE component reaches.  There every responsibility is 1 and a row's log-density is that component's:
 // no log-sum-exp, nothing to exchange between waves, no LDS staging and no barrier.  Every wave works through its own
 // lists of tiles (fullcov_tilelists) by itself, one component after the other: it loads the rows of a tile straight
@@ -1243,7 +1283,8 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
     const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials,
-    const int* __restrict__ tlist, const int* __restrict__ toff, int cap) {
+    const int* __restrict__ tlist, const int* __restrict__ toff, int cap, const unsigned char* __restrict__ phi,
+    const unsigned char* __restrict__ plo) {
   __shared__ float sqw[FW][FT];
   __shared__ double lpw[FW];
   // column centres and scales: read from LDS where they are used (registers are short)
@@ -1259,23 +1300,13 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   float* out = partials + (((int64_t)blockIdx.x * R + rep) * C + c) * ((int64_t)K * Q + 1);
   double logp_acc = 0.0;
   const float row_level = fullcov_row_level(cst + (int64_t)c * K, K, D);
-  const bool vec_ok = D == DP && (((uintptr_t)Y & 15) == 0);
-  f32x4 raw[4][2];
-  auto gload = [&](int64_t tile) {          // rows 16 rt + ln of the tile, dims 8 g .. 8 g + 7; past the end: the centre
+  f16x8 rawh[4], rawl[4];
+  auto gload = [&](int64_t tile) {          // rows 16 rt + ln of the tile, dims 8 g .. 8 g + 7, both pieces
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const int64_t gr = tile * FT + 16 * rt + ln;
-      if (vec_ok && gr < n) {
-        raw[rt][0] = *reinterpret_cast<const f32x4*>(Y + gr * DP + 8 * g);
-        raw[rt][1] = *reinterpret_cast<const f32x4*>(Y + gr * DP + 8 * g + 4);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bool in = gr < n && 8 * g + e < D;
-          const float y = Y[in ? gr * D + 8 * g + e : 0];      // (a tile exists, so Y[0] does)
-          raw[rt][e >> 2][e & 3] = in ? y : cms[0][8 * g + e];
-        }
-      }
+      const int64_t off = (tile * FT + 16 * rt + ln) * 64 + 16 * g;
+      rawh[rt] = *reinterpret_cast<const f16x8*>(phi + off);
+      rawl[rt] = *reinterpret_cast<const f16x8*>(plo + off);
     }
   };
   const int* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
@@ -1335,25 +1366,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       gload(tile);
     }
     for (; li < li1; ++li) {
-      // the tile's rows as f16 pieces (A operands); the staging registers are then free for the next tile's rows
+      // the tile's rows (A operands); the staging registers are then free for the next tile's rows
       f16x8 fh[4], fl[4];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x4 cm = *reinterpret_cast<const f32x4*>(&cms[0][8 * g + 4 * h]);
-          const f32x4 cs = *reinterpret_cast<const f32x4*>(&cms[1][8 * g + 4 * h]);
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const float q0 = (raw[rt][h][e] - cm[e]) * cs[e];
-            const float q1 = (raw[rt][h][e + 1] - cm[e + 1]) * cs[e + 1];
-            fc_split_pair(q0, q1, hw[2 * h + (e >> 1)], lw[2 * h + (e >> 1)]);
-          }
-        }
-        fh[rt] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
-        fl[rt] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
-      }
+      for (int rt = 0; rt < 4; ++rt) { fh[rt] = rawh[rt]; fl[rt] = rawl[rt]; }
       const int64_t tile_cur = tile;
       if (li + 1 < li1) {
         tile = seg[li + 1];
@@ -1588,9 +1604,10 @@ size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t lists = (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
   const size_t listsg = (size_t)c * nbg * ((size_t)fullcov_list_cap(n, (int)nbg) + kListOffs);
   const size_t ngroups = (ntiles + 63) / 64;
+  // + the flag "some tile is on a single-component list" and the two f16 planes of the rows (16-B aligned)
   return (ntiles + ngroups) * (DP + 1) + 2 * (size_t)c * k + 2 * (size_t)c * ngroups * k + 2 +
          ((size_t)c * ntiles + 1) / 2 + 2 +
-         (lists > listsg ? lists : listsg);
+         (lists > listsg ? lists : listsg) + 8 + ntiles * FT * DP;
 }
 
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
@@ -1630,6 +1647,10 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   unsigned short* tmask = reinterpret_cast<unsigned short*>(gb0 + 2 * (size_t)c * ngroups * k);
   int* tlist = reinterpret_cast<int*>(gb0 + 2 * (size_t)c * ngroups * k + ((size_t)c * ntiles + 1) / 2 + 2);
   int* toff = tlist + (size_t)c * nblk * cap;
+  int* any_single = toff + (size_t)c * nblk * kListOffs;
+  any_single += (4 - (((uintptr_t)any_single >> 2) & 3)) & 3;            // 16-B aligned; the planes follow at + 16 B
+  unsigned char* phi = reinterpret_cast<unsigned char*>(any_single + 4);
+  unsigned char* plo = phi + (size_t)ntiles * FT * DP * 2;
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
   static const bool use_f32 = getenv("BVI_FULLCOV_F32") && atoi(getenv("BVI_FULLCOV_F32")) != 0;
@@ -1682,8 +1703,15 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     const unsigned short* tmask_arg = prune ? tmask : nullptr;
     // one component: every tile is a single-component tile; no pruning otherwise: none is
     const bool lists_from_masks = prune || k == 1;
+    hipError_t me = hipMemsetAsync(any_single, 0, sizeof(int), s);
+    if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(fullcov_tilelists, dim3(nblk, c), dim3(64), 0, s, lists_from_masks ? tmask_arg : (const unsigned short*)nullptr,
-                       ntiles, lists_from_masks ? k : 16, cap, tlist, toff);
+                       ntiles, lists_from_masks ? k : 16, cap, tlist, toff, any_single);
+    if (ntiles > 0) {
+      const int pblocks = (int)(ntiles > 4096 ? 4096 : ntiles);
+      hipLaunchKernelGGL(fullcov_planes, dim3(pblocks), dim3(256), 0, s, Y, n, d, ntiles, (const float*)center,
+                         (const float*)cscale, (const int*)any_single, phi, plo);
+    }
     BVI_HIP_CHECK_LAUNCH();
 #define BVI_FC16D(KQ, GRAD, PRUNE)                                                                                  \
   hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD, PRUNE>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,    \
@@ -1694,7 +1722,8 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   if (prune) BVI_FC16D(KQ, GRAD, true);                                                                              \
   hipLaunchKernelGGL((fullcov_single_kernel<GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,            \
                      (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
-                     c, partials + (size_t)nblk * pstride, (const int*)tlist, (const int*)toff, cap)
+                     c, partials + (size_t)nblk * pstride, (const int*)tlist, (const int*)toff, cap,                      \
+                     (const unsigned char*)phi, (const unsigned char*)plo)
     if (k <= FW) {
       if (grad) { BVI_FC16(1, true); } else { BVI_FC16(1, false); }
     } else {
