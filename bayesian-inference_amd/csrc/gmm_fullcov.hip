@@ -84,11 +84,15 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
 //   anorm  = an upper bound of the spectral norm of A: |A|_2^2 = lambda_max(M), M = A^T A, and lambda_max(M)^8 =
 //            lambda_max(M^8) <= |M^8|_F, which is within DP^(1/16) = 1.24 of it -- three squarings in float, each
 //            normalised by its largest entry;
-//   mudist = |mu_k - center|.
+//   mudist = |mu_k - center|;
+//   lnorm  = an upper bound of the spectral norm of L = A^-1 (so that |A v| >= |v| / lnorm): sqrt(|L|_1 |L|_inf),
+//            the largest column sum times the largest row sum of |L| -- looser than anorm's, and enough for what it
+//            is used for (telling components many widths away from a tile apart from the one the tile belongs to).
 // One workgroup of 256 threads per (chain, component): thread (rg, j) owns rows rg, rg + 8, ... of column j.
 __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ theta, int K, int D,
                                                      const float* __restrict__ center, const float* __restrict__ Ainv,
-                                                     float* __restrict__ anorm, float* __restrict__ mudist) {
+                                                     float* __restrict__ anorm, float* __restrict__ mudist,
+                                                     float* __restrict__ lnorm) {
   const int c = blockIdx.x / K, k = blockIdx.x % K, tid = threadIdx.x, j = tid & (DP - 1), rg = tid / DP;
   const int P = K + K * D + K * D * D;
   const float* mu = theta + (int64_t)c * P + K + k * D;
@@ -110,6 +114,18 @@ __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ t
   const float dmu = (rg == 0 && j < D) ? mu[j] - center[j] : 0.f;
   const float md2 = block_reduce(dmu * dmu, false);     // (its barriers also publish Af)
   if (tid == 0) mudist[c * K + k] = sqrtf(md2);
+  {
+    const float* L = theta + (int64_t)c * P + K + K * D + (int64_t)k * D * D;
+    float rs = 0.f, csm = 0.f;                          // row j and column j of |L| (lower triangle)
+    if (rg == 0 && j < D) {
+      for (int m = 0; m <= j; ++m) rs += fabsf(L[j * D + m]);
+      for (int i = j; i < D; ++i) csm += fabsf(L[i * D + j]);
+    }
+    const float rmax = block_reduce(rs, true), cmx = block_reduce(csm, true);
+    // (a NaN entry is lost in the maxima: the sum below brings it back)
+    const float chk = block_reduce(rg == 0 && j < D ? rs - rs : 0.f, false);
+    if (tid == 0) lnorm[c * K + k] = sqrtf(rmax * cmx) * 1.0001f + chk;
+  }
   float cmax = 0.f;
   for (int i = rg; i < DP; i += 8) {
     float v = 0.f;
@@ -151,72 +167,99 @@ __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ t
 // One pass over Y for both kinds of statistics.  Per 64-row tile: centre (column means) and radius (largest distance
 // of a row from the centre), raw coordinates: tstat[tile][0 .. DP-1] = centre, [DP] = radius (tstat == nullptr: not
 // wanted).  Per column: sum (double), min, max over the rows of this workgroup's tiles, psum / pmin / pmax[block][DP]
-// (the first stage of the column statistics; fullcov_colstats_final is the second).  One wave per tile, lane = row;
-// a workgroup's four waves stride over the tiles.
+// (the first stage of the column statistics; fullcov_colstats_final is the second).  One wave per tile; lane
+// (ln, g) = (lane & 15, lane >> 4) holds columns 8 g .. 8 g + 7 of rows ln, ln + 16, ln + 32, ln + 48 (a row is one
+// contiguous 128 B across g); column sums run down the 16 lanes of a DPP row, a row's distance across g.  A
+// workgroup's four waves stride over the tiles.
+__device__ __forceinline__ float tilestats_row16_sum(float v) {       // sum over the 16 lanes of a DPP row, in every lane
+#define BVI_TS_STEP(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+  BVI_TS_STEP(0xB1);       // quad_perm [1, 0, 3, 2]
+  BVI_TS_STEP(0x4E);       // quad_perm [2, 3, 0, 1]
+  BVI_TS_STEP(0x124);      // row_ror 4
+  BVI_TS_STEP(0x128);      // row_ror 8
+#undef BVI_TS_STEP
+  return v;
+}
 __global__ __launch_bounds__(256) void fullcov_tilestats(const float* __restrict__ Y, int64_t n, int D, int64_t ntiles,
                                                          float* __restrict__ tstat, double* __restrict__ psum,
                                                          float* __restrict__ pmin, float* __restrict__ pmax) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, g = lane >> 4;
   const bool vec_ok = D == DP && (((uintptr_t)Y & 15) == 0);
-  double csum = 0.0;                                   // lane d < DP: column d
-  float mn[DP], mx[DP];                                // this lane's rows
+  double csum[8];                                      // lanes with ln == 0: columns 8 g + e
+  float mn[8], mx[8];                                  // this lane's rows
 #pragma unroll
-  for (int d = 0; d < DP; ++d) { mn[d] = INFINITY; mx[d] = -INFINITY; }
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.0; mn[e] = INFINITY; mx[e] = -INFINITY; }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t row = tile * 64 + lane;
-    const bool valid = row < n;
     const int64_t left = n - tile * 64;
     const float icnt = 1.f / (float)(left < 64 ? left : 64);
-    float y[DP];
-    if (vec_ok) {
+    float y[4][8];
+    bool valid[4];
 #pragma unroll
-      for (int q = 0; q < DP / 4; ++q) {
-        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
-        if (valid) t4 = *reinterpret_cast<const f32x4*>(Y + row * DP + 4 * q);
+    for (int rt = 0; rt < 4; ++rt) {
+      const int64_t row = tile * 64 + 16 * rt + ln;
+      valid[rt] = row < n;
+      if (vec_ok) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (valid[rt]) {
+          a = *reinterpret_cast<const f32x4*>(Y + row * DP + 8 * g);
+          b = *reinterpret_cast<const f32x4*>(Y + row * DP + 8 * g + 4);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[4 * q + e] = t4[e];
+        for (int e = 0; e < 4; ++e) { y[rt][e] = a[e]; y[rt][4 + e] = b[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[rt][e] = (valid[rt] && 8 * g + e < D) ? Y[row * D + 8 * g + e] : 0.f;
       }
-    } else {
-#pragma unroll
-      for (int d = 0; d < DP; ++d) y[d] = (valid && d < D) ? Y[row * D + d] : 0.f;
     }
-    float dist2 = 0.f;
+    float m[8];
 #pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      if (valid) { mn[d] = fminf(mn[d], y[d]); mx[d] = fmaxf(mx[d], y[d]); }
-      float sm = y[d];
+    for (int e = 0; e < 8; ++e) {
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
-      const float m = sm * icnt;
-      if (lane == d) {
-        csum += (double)sm;
-        if (tstat) tstat[tile * (DP + 1) + d] = m;
+      for (int rt = 0; rt < 4; ++rt)
+        if (valid[rt]) { mn[e] = fminf(mn[e], y[rt][e]); mx[e] = fmaxf(mx[e], y[rt][e]); }
+      const float sm = tilestats_row16_sum((y[0][e] + y[1][e]) + (y[2][e] + y[3][e]));
+      m[e] = sm * icnt;
+      csum[e] += (double)sm;                           // (kept by the lanes with ln == 0)
+    }
+    if (tstat && ln == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tstat[tile * (DP + 1) + 8 * g + e] = m[e];
+    }
+    float dmax = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      float d2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dv = valid[rt] ? y[rt][e] - m[e] : 0.f;
+        d2 = fmaf(dv, dv, d2);
       }
-      const float e = valid ? y[d] - m : 0.f;
-      dist2 = fmaf(e, e, dist2);
+      d2 += __shfl_xor(d2, 16, 64);
+      d2 += __shfl_xor(d2, 32, 64);
+      dmax = (d2 > dmax || d2 != d2) ? d2 : dmax;        // NaN wins: such a tile keeps every component
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float o = __shfl_xor(dist2, off, 64);
-      dist2 = (o > dist2 || o != o) ? o : dist2;         // NaN wins: such a tile keeps every component
+    for (int off = 8; off >= 1; off >>= 1) {
+      const float o = __shfl_xor(dmax, off, 64);
+      dmax = (o > dmax || o != o) ? o : dmax;
     }
-    if (lane == 0 && tstat) tstat[tile * (DP + 1) + DP] = sqrtf(dist2);
+    if (lane == 0 && tstat) tstat[tile * (DP + 1) + DP] = sqrtf(dmax);
   }
-  // column minima / maxima over the wave's rows (lane d keeps column d), then over the four waves
-  float cmn = INFINITY, cmx = -INFINITY;
+  // column minima / maxima over the wave's rows (down the 16 lanes of a DPP row), then over the four waves
 #pragma unroll
-  for (int d = 0; d < DP; ++d) {
-    float a = mn[d], b = mx[d];
+  for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      a = fminf(a, __shfl_xor(a, off, 64));
-      b = fmaxf(b, __shfl_xor(b, off, 64));
+    for (int off = 8; off >= 1; off >>= 1) {
+      mn[e] = fminf(mn[e], __shfl_xor(mn[e], off, 64));
+      mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], off, 64));
     }
-    if (lane == d) { cmn = a; cmx = b; }
-  }
   __shared__ double ssum[4][DP];
   __shared__ float smn[4][DP], smx[4][DP];
-  if (lane < DP) { ssum[wave][lane] = csum; smn[wave][lane] = cmn; smx[wave][lane] = cmx; }
+  if (ln == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[wave][8 * g + e] = csum[e]; smn[wave][8 * g + e] = mn[e]; smx[wave][8 * g + e] = mx[e]; }
+  }
   __syncthreads();
   if (threadIdx.x < DP) {
     const int d = threadIdx.x;
@@ -316,16 +359,23 @@ __global__ __launch_bounds__(64) void fullcov_group_bounds(const float* __restri
 // hi / lo = |u_k(m)| +- anorm_k r.  A component whose upper bound is more than 32 below the largest lower bound has
 // responsibilities below e^-32 = 2^-46 for every row of the sphere: bit k of mask[chain][sphere] is cleared and the
 // streaming kernels do not evaluate it there (its terms are below the 2^-40 the raw-sums phase keeps anyway).
-// Anything non-finite keeps the bit set.  One thread per sphere:
+// Anything non-finite keeps the bit set.  One thread per tile, one wave per group of 64 tiles, in three steps of
+// rising cost, each only for what the one before left open:
 //   1. without any product: |u_k(m)| <= anorm_k (|m - centre| + |mu_k - centre|) bounds lo_k from above and
 //      hi_j >= anorm_j r bounds the largest lower bound from above; if that already keeps every component (rows in
-//      no particular order: r is the size of the whole dataset) the sphere is done;
-//   2. the test itself, only for the components the sphere's group of 64 kept (`parent`: the group's bounds from
-//      fullcov_group_bounds; with rows stored cluster by cluster most components are ruled out for 64 tiles at once).
-__global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K,
+//      no particular order: r is the size of the whole dataset) the tile keeps what its group kept (`parent`: the
+//      group's bounds from fullcov_group_bounds; with rows stored cluster by cluster most groups keep one component,
+//      which settles all their tiles);
+//   2. from the distance to the component's mean alone (D multiplications per component):
+//      |m - mu_k| / lnorm_k <= |u_k(m)| <= anorm_k |m - mu_k|.  A tile in the middle of its cluster is left with that
+//      cluster's component; a tile that straddles two clusters (one per boundary) keeps many, and stays as it is;
+//   3. |u_k(m)| itself (D^2 / 2 multiplications, A_k through LDS, every lane reading the same element), only when
+//      some tile of the wave is left with two or three components by step 2: overlapping clusters.
+__global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K, int D,
+                                                      const float* __restrict__ theta,
                                                       const float* __restrict__ Ainv, const float* __restrict__ bvec,
                                                       const float* __restrict__ cst, const float* __restrict__ anorm,
-                                                      const float* __restrict__ mudist,
+                                                      const float* __restrict__ mudist, const float* __restrict__ lnorm,
                                                       const float* __restrict__ center, int C,
                                                       const float2* __restrict__ parent, int64_t nparent,
                                                       unsigned short* __restrict__ mask_out) {
@@ -334,6 +384,7 @@ __global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ t
   __shared__ float aub[16][64];
   __shared__ __attribute__((aligned(16))) float As[DP * DP];
   __shared__ float bs[DP];
+  __shared__ __attribute__((aligned(16))) float mus[16][DP];     // mu_k - centre
   const bool tv = t < ntiles;
   const float* ts = tstat + (tv ? t : 0) * (DP + 1);
   float dm[DP];
@@ -345,73 +396,126 @@ __global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ t
   }
   const float r = ts[DP];
   const unsigned full = (1u << K) - 1u;
+  // the chain's per-component numbers and the parent's bounds: lane k holds component k's (one coalesced load each;
+  // read back by readlane -- as scalar loads inside the loops they were a chain of K waits)
+  const int kl = lane < K ? lane : 0;
+  const float an_l = anorm[c * K + kl], ck_l = cst[c * K + kl], md_l = mudist[c * K + kl], ln_l = lnorm[c * K + kl];
+  float2 pb_l = make_float2(INFINITY, -INFINITY);
+  if (parent) pb_l = parent[((int64_t)c * nparent + (t - lane) / 64) * K + kl];
   // 1.
   bool keeps_all = true;
   {
     const float dn = sqrtf(dn2);
     float top = -INFINITY, low = INFINITY;            // upper bound of the largest lower bound; smallest a_ub bound
     for (int k = 0; k < K; ++k) {
-      const float an = anorm[c * K + k], ck = cst[c * K + k];
+      const float an = __shfl(an_l, k, 64), ck = __shfl(ck_l, k, 64);
       const float sl = an * r;
-      const float lomax = fmaxf(an * (dn + mudist[c * K + k]) * 1.001f + 1e-3f - sl, 0.f);
+      const float lomax = fmaxf(an * (dn + __shfl(md_l, k, 64)) * 1.001f + 1e-3f - sl, 0.f);
       top = fmaxf(top, ck - 0.5f * sl * sl);
       low = fminf(low, ck - 0.5f * lomax * lomax);
     }
     keeps_all = !(low < top - 30.f);                  // (NaN: keeps everything)
   }
-  // 2.  The components this wave's 64 spheres still have to test (they share a parent); A_k goes through LDS, one
-  //     component at a time (every lane reads the same element: a broadcast read).
-  unsigned sup = 0;
-  if (__builtin_amdgcn_ballot_w64(tv && !keeps_all) != 0) {
-    sup = full;
-    if (parent) {                                       // the group's mask from its components' bounds
-      const float2* pb = parent + ((int64_t)c * nparent + (t - lane) / 64) * K;
-      float gbest = -INFINITY;
-      for (int k = 0; k < K; ++k) gbest = fmaxf(gbest, pb[k].y);
-      const float gth = gbest - 32.f - 1e-4f * fabsf(gbest);
-      sup = 0;
-      for (int k = 0; k < K; ++k)
-        if (!(pb[k].x < gth)) sup |= 1u << k;
-      sup = __builtin_amdgcn_readfirstlane(sup);
-    }
-  }
-  float best = -INFINITY;
-  bool odd = false;                      // something is not finite: keep everything the parent kept
-  for (int k = 0; k < K; ++k) {
-    if (!((sup >> k) & 1u)) continue;    // (the same for the whole wave)
-    __syncthreads();                     // the previous component's readers are done
+  unsigned sup = full;
+  if (parent) {                                         // the group's mask from its components' bounds
+    float gbest = lane < K ? pb_l.y : -INFINITY;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f32x4*>(&As[4 * (lane + 64 * q)]) =
-          *reinterpret_cast<const f32x4*>(Ainv + ((int64_t)c * K + k) * DP * DP + 4 * (lane + 64 * q));
-    if (lane < DP) bs[lane] = bvec[((int64_t)c * K + k) * DP + lane];
+    for (int off = 8; off >= 1; off >>= 1) gbest = fmaxf(gbest, __shfl_xor(gbest, off, 64));
+    gbest = __shfl(gbest, 0, 64);
+    const float gth = gbest - 32.f - 1e-4f * fabsf(gbest);
+    sup = (unsigned)__builtin_amdgcn_ballot_w64(lane < K && !(pb_l.x < gth));
+  }
+  unsigned mask = sup;
+  // 2. (the same decision in every lane: the barriers below are met by all)
+  if (__builtin_popcount(sup) > 1 && __builtin_amdgcn_ballot_w64(tv && !keeps_all) != 0) {
+    const int P = K + K * D + K * D * D;
+    for (int e = lane; e < K * DP; e += 64) {
+      const int k = e / DP, d = e % DP;
+      mus[k][d] = d < D ? theta[(int64_t)c * P + K + k * D + d] - center[d] : 0.f;
+    }
     __syncthreads();
-    float d2 = 0.f;
+    float best = -INFINITY;
+    unsigned open = 0;                                  // components whose cheap bounds are finite
+    float ubc[16];
 #pragma unroll
-    for (int i = 0; i < DP; ++i) {
-      float sacc = -bs[i];
+    for (int k = 0; k < 16; ++k) {
+      ubc[k] = INFINITY;
+      if (k < K && ((sup >> k) & 1u)) {                 // (the same for the whole wave)
+        float d2 = 0.f;
 #pragma unroll
-      for (int j4 = 0; j4 <= i; j4 += 4) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[i * DP + j4]);
+        for (int q = 0; q < DP / 4; ++q) {
+          const f32x4 m4 = *reinterpret_cast<const f32x4*>(&mus[k][4 * q]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (j4 + e <= i) sacc = fmaf(a4[e], dm[j4 + e], sacc);
+          for (int e = 0; e < 4; ++e) {
+            const float dv = dm[4 * q + e] - m4[e];
+            d2 = fmaf(dv, dv, d2);
+          }
+        }
+        const float dist = sqrtf(d2), an = __shfl(an_l, k, 64), ck = __shfl(ck_l, k, 64);
+        const float slack = an * r * 1.001f + 1e-3f;
+        const float lo = fmaxf(dist / __shfl(ln_l, k, 64) * 0.999f - slack, 0.f), hi = an * dist * 1.001f + slack;
+        const float ub = ck - 0.5f * lo * lo, lb = ck - 0.5f * hi * hi;
+        if ((fabsf(ub) < INFINITY) && (fabsf(lb) < INFINITY)) {
+          ubc[k] = ub;
+          open |= 1u << k;
+          best = fmaxf(best, lb);
+        } else if (!(ck > -INFINITY || ck != ck)) {
+          ubc[k] = -INFINITY;                           // weight 0: out of reach everywhere
+        }
       }
-      d2 = fmaf(sacc, sacc, d2);
     }
-    const float dk = sqrtf(d2), slack = anorm[c * K + k] * r * 1.001f + 1e-3f;
-    const float lo = fmaxf(dk - slack, 0.f), hi = dk + slack;
-    const float ck = cst[c * K + k];
-    const float ub = ck - 0.5f * lo * lo, lb = ck - 0.5f * hi * hi;
-    aub[k][threadIdx.x] = ub;
-    if (lb > best) best = lb;
-    if (!(fabsf(ub) < INFINITY) || !(fabsf(lb) < INFINITY)) odd = odd || (ck > -INFINITY);
+    const float th2 = best - 32.f - 1e-4f * fabsf(best);
+    unsigned m2 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < K && ((sup >> k) & 1u) && !(ubc[k] < th2)) m2 |= 1u << k;
+    if (!keeps_all) mask = m2;
+    // 3.
+    const bool refine = tv && !keeps_all && __builtin_popcount(m2) >= 2 && __builtin_popcount(m2) <= 3 &&
+                        (m2 & ~open) == 0;
+    unsigned supx = 0;
+    for (int k = 0; k < K; ++k)
+      if (__builtin_amdgcn_ballot_w64(refine && ((m2 >> k) & 1u)) != 0) supx |= 1u << k;
+    float bestx = -INFINITY;
+    bool odd = false;                      // something is not finite: keep what step 2 kept
+    for (int k = 0; k < K; ++k) {
+      if (!((supx >> k) & 1u)) continue;   // (the same for the whole wave)
+      __syncthreads();                     // the previous component's readers are done
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(&As[4 * (lane + 64 * q)]) =
+            *reinterpret_cast<const f32x4*>(Ainv + ((int64_t)c * K + k) * DP * DP + 4 * (lane + 64 * q));
+      if (lane < DP) bs[lane] = bvec[((int64_t)c * K + k) * DP + lane];
+      __syncthreads();
+      float d2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < DP; ++i) {
+        float sacc = -bs[i];
+#pragma unroll
+        for (int j4 = 0; j4 <= i; j4 += 4) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(&As[i * DP + j4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (j4 + e <= i) sacc = fmaf(a4[e], dm[j4 + e], sacc);
+        }
+        d2 = fmaf(sacc, sacc, d2);
+      }
+      const float dk = sqrtf(d2), slack = __shfl(an_l, k, 64) * r * 1.001f + 1e-3f;
+      const float lo = fmaxf(dk - slack, 0.f), hi = dk + slack;
+      const float ck = __shfl(ck_l, k, 64);
+      const float ub = ck - 0.5f * lo * lo, lb = ck - 0.5f * hi * hi;
+      aub[k][threadIdx.x] = ub;
+      if (lb > bestx) bestx = lb;
+      if (!(fabsf(ub) < INFINITY) || !(fabsf(lb) < INFINITY)) odd = true;
+    }
+    if (refine && !odd) {
+      const float th3 = bestx - 32.f - 1e-4f * fabsf(bestx);
+      unsigned m3 = 0;
+      for (int k = 0; k < K; ++k)
+        if (((m2 >> k) & 1u) && !(aub[k][threadIdx.x] < th3)) m3 |= 1u << k;
+      mask = m3;
+    }
   }
-  const float thresh = best - 32.f - 1e-4f * fabsf(best);
-  unsigned mask = 0;
-  for (int k = 0; k < K; ++k)
-    if (((sup >> k) & 1u) && (odd || !(aub[k][threadIdx.x] < thresh))) mask |= 1u << k;
-  if (keeps_all) mask = full;
   if (tv) mask_out[(int64_t)c * ntiles + t] = (unsigned short)mask;
 }
 
@@ -1361,10 +1465,12 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     int li = so[wave + FW * q];
     const int li1 = so[wave + FW * q + 1];
     int64_t tile = 0;
+    int tile_after = 0;                      // list entry li + 2: read a whole tile before its rows are asked for
     if (li < li1) {
       tile = seg[li];
       gload(tile);
     }
+    if (li + 1 < li1) tile_after = seg[li + 1];
     for (; li < li1; ++li) {
       // the tile's rows (A operands); the staging registers are then free for the next tile's rows
       f16x8 fh[4], fl[4];
@@ -1372,9 +1478,10 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       for (int rt = 0; rt < 4; ++rt) { fh[rt] = rawh[rt]; fl[rt] = rawl[rt]; }
       const int64_t tile_cur = tile;
       if (li + 1 < li1) {
-        tile = seg[li + 1];
+        tile = tile_after;
         gload(tile);
       }
+      if (li + 2 < li1) tile_after = seg[li + 2];
       f32x4 u[GRAD ? 4 : 1][2];
       f32x4 zc[2], zn[2];
       float arow[4];                         // log-density of row 16 rt + 4 g + (ln >> 2)
@@ -1605,7 +1712,7 @@ size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t listsg = (size_t)c * nbg * ((size_t)fullcov_list_cap(n, (int)nbg) + kListOffs);
   const size_t ngroups = (ntiles + 63) / 64;
   // + the flag "some tile is on a single-component list" and the two f16 planes of the rows (16-B aligned)
-  return (ntiles + ngroups) * (DP + 1) + 2 * (size_t)c * k + 2 * (size_t)c * ngroups * k + 2 +
+  return (ntiles + ngroups) * (DP + 1) + 3 * (size_t)c * k + 2 * (size_t)c * ngroups * k + 2 +
          ((size_t)c * ntiles + 1) / 2 + 2 +
          (lists > listsg ? lists : listsg) + 8 + ntiles * FT * DP;
 }
@@ -1641,7 +1748,8 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   float* gstat = tstat + (size_t)ntiles * (DP + 1);
   float* anorm = gstat + (size_t)ngroups * (DP + 1);
   float* mudist = anorm + (size_t)c * k;
-  float* gb0 = mudist + (size_t)c * k;
+  float* lnorm = mudist + (size_t)c * k;
+  float* gb0 = lnorm + (size_t)c * k;
   gb0 += ((uintptr_t)gb0 & 7) ? 1 : 0;                 // float2 entries
   float2* gbounds = reinterpret_cast<float2*>(gb0);
   unsigned short* tmask = reinterpret_cast<unsigned short*>(gb0 + 2 * (size_t)c * ngroups * k);
@@ -1690,14 +1798,15 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     BVI_HIP_CHECK_LAUNCH();
     if (prune) {
       hipLaunchKernelGGL(fullcov_anorm, dim3(c * k), dim3(256), 0, s, theta, k, d, (const float*)center, (const float*)Ainv,
-                         anorm, mudist);
+                         anorm, mudist, lnorm);
       hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
       hipLaunchKernelGGL(fullcov_group_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 64), c, k), dim3(64), 0, s,
                          (const float*)gstat, ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst,
                          (const float*)anorm, (const float*)center, gbounds);
       hipLaunchKernelGGL(fullcov_bounds, dim3((unsigned)bvi_ceil_div(ntiles, 64), c), dim3(64), 0, s, (const float*)tstat,
-                         ntiles, k, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
-                         (const float*)mudist, (const float*)center, c, (const float2*)gbounds, ngroups, tmask);
+                         ntiles, k, d, theta, (const float*)Ainv, (const float*)bvec, (const float*)cst, (const float*)anorm,
+                         (const float*)mudist, (const float*)lnorm, (const float*)center, c, (const float2*)gbounds, ngroups,
+                         tmask);
       BVI_HIP_CHECK_LAUNCH();
     }
     const unsigned short* tmask_arg = prune ? tmask : nullptr;
