@@ -21,7 +21,7 @@ PRIOR_NONE, PRIOR_NORMAL, PRIOR_HALFNORMAL, PRIOR_DIRICHLET, PRIOR_WISHART_TRIL 
 MAX_PARAM_BLOCKS = 16
 NOALLOC_MAX_CHAINS = 256
 ERR_TOO_LARGE = -4
-ABI_VERSION = 111     # BVI_VERSION of include/bvi.h this binding was written against
+ABI_VERSION = 112     # BVI_VERSION of include/bvi.h this binding was written against
 
 
 class ParamBlock(ctypes.Structure):
@@ -78,6 +78,11 @@ def lib():
         l.bvi_normal_iid_logp_grad_noalloc.restype = i32
         l.bvi_gmm1d_logp_grad.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_gmm_fullcov_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_gmm_fullcov_packed_bytes.argtypes = [i64, i32, ctypes.POINTER(sz)]
+        l.bvi_gmm_fullcov_pack_scratch_bytes.argtypes = [i32, ctypes.POINTER(sz)]
+        l.bvi_gmm_fullcov_pack.argtypes = [vp, i64, i32, vp, sz, vp, sz, vp]
+        l.bvi_gmm_fullcov_packed_logp_grad.argtypes = [vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+        l.bvi_mvn_tril_packed_logp_grad.argtypes = [vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
         l.bvi_cluster_rows_scratch_bytes.argtypes = [i64, i32, i32, ctypes.POINTER(sz)]
         l.bvi_cluster_rows.argtypes = [vp, i64, i32, i32, vp, vp, vp, sz, vp]
         l.bvi_mvn_tril_logp_grad.argtypes = [vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
@@ -299,13 +304,19 @@ def philox_normal(seed, step, n_chains, n_params, device):
     return out
 
 
-def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True, logp_ref=None):
+def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True, logp_ref=None, packed=None):
+    """bvi_gmm_fullcov_logp_grad, or bvi_gmm_fullcov_packed_logp_grad with `packed` = gmm_fullcov_pack(Y)."""
     _check_f32_cuda(Y, theta)
     n, d = Y.shape
     c = theta.shape[0]
     assert theta.shape == (c, k + k * d + k * d * d)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_GMM_FULLCOV, n, c, d=d, k=k))
+    if packed is not None:
+        check(lib().bvi_gmm_fullcov_packed_logp_grad(_ptr(Y), _ptr(packed), n, d, k, _ptr(theta), c, _ptr(logp),
+                                                     _ptr(grad), _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()),
+              'bvi_gmm_fullcov_packed_logp_grad')
+        return logp, grad
     check(lib().bvi_gmm_fullcov_logp_grad(_ptr(Y), n, d, k, _ptr(theta), c, _ptr(logp), _ptr(grad),
                                           _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()),
           'bvi_gmm_fullcov_logp_grad')
@@ -313,6 +324,21 @@ def gmm_fullcov_logp_grad(Y, theta, k, ws: Workspace, want_grad=True, logp_ref=N
 
 
 CLUSTER_MAX_CENTRES = 128
+
+
+def gmm_fullcov_pack(Y):
+    """bvi_gmm_fullcov_pack: what the full-covariance mixture / multivariate-normal entry points need of the rows
+    alone (statistics, tile spheres, f16 pieces), once per dataset."""
+    _check_f32_cuda(Y)
+    n, d = Y.shape
+    out = ctypes.c_size_t(0)
+    check(lib().bvi_gmm_fullcov_packed_bytes(n, d, ctypes.byref(out)), 'bvi_gmm_fullcov_packed_bytes')
+    packed = torch.empty(max(int(out.value), 16), dtype=torch.uint8, device=Y.device)
+    check(lib().bvi_gmm_fullcov_pack_scratch_bytes(d, ctypes.byref(out)), 'bvi_gmm_fullcov_pack_scratch_bytes')
+    scratch = torch.empty(max(int(out.value), 16), dtype=torch.uint8, device=Y.device)
+    check(lib().bvi_gmm_fullcov_pack(_ptr(Y), n, d, _ptr(packed), packed.numel(), _ptr(scratch), scratch.numel(),
+                                     _stream()), 'bvi_gmm_fullcov_pack')
+    return packed
 
 
 def cluster_rows(Y, n_centres, want_order=False):
@@ -331,7 +357,7 @@ def cluster_rows(Y, n_centres, want_order=False):
     return (Yout, order) if want_order else Yout
 
 
-def mvn_tril_logp_grad(Y, theta, parameterisation, ws: Workspace, want_grad=True, logp_ref=None):
+def mvn_tril_logp_grad(Y, theta, parameterisation, ws: Workspace, want_grad=True, logp_ref=None, packed=None):
     """bvi_mvn_tril_logp_grad: Y[n, d], theta[C, d + d*d] = (loc, M) with M the scale (MVN_SCALE_TRIL) or a Cholesky
     factor of the precision as the reference passes it (MVN_CHOL_PRECISION_SOLVE)."""
     _check_f32_cuda(Y, theta)
@@ -340,6 +366,11 @@ def mvn_tril_logp_grad(Y, theta, parameterisation, ws: Workspace, want_grad=True
     assert theta.shape == (c, d + d * d)
     logp, grad = _outputs(theta, want_grad)
     buf = ws.get(workspace_bytes(FAMILY_MVN_TRIL, n, c, d=d))
+    if packed is not None:
+        check(lib().bvi_mvn_tril_packed_logp_grad(_ptr(Y), _ptr(packed), n, d, int(parameterisation), _ptr(theta), c,
+                                                  _ptr(logp), _ptr(grad), _ref_ptr(logp_ref), _ptr(buf), buf.numel(),
+                                                  _stream()), 'bvi_mvn_tril_packed_logp_grad')
+        return logp, grad
     check(lib().bvi_mvn_tril_logp_grad(_ptr(Y), n, d, int(parameterisation), _ptr(theta), c, _ptr(logp), _ptr(grad),
                                        _ref_ptr(logp_ref), _ptr(buf), buf.numel(), _stream()), 'bvi_mvn_tril_logp_grad')
     return logp, grad

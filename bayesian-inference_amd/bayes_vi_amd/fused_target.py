@@ -253,13 +253,20 @@ class GaussianMixtureFullCov(FusedLogLikelihood):
         self.n, self.d = self.Y.shape
         self.k = int(k)
         self.n_params = self.k * (1 + self.d + self.d * self.d)
+        # what the kernels need of the rows alone (statistics, tile spheres, f16 pieces): once, not per evaluation
+        self.packed = _native.gmm_fullcov_pack(self.Y) if self.n > 0 else None
 
     def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d, k=self.k))
-        _launch(_native.lib().bvi_gmm_fullcov_logp_grad, _native._ptr(self.Y), self.n, self.d, self.k,
-                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf),
-                buf.numel(), _native._stream())
+        if self.packed is None:
+            _launch(_native.lib().bvi_gmm_fullcov_logp_grad, _native._ptr(self.Y), self.n, self.d, self.k,
+                    _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative),
+                    _native._ptr(buf), buf.numel(), _native._stream())
+            return
+        _launch(_native.lib().bvi_gmm_fullcov_packed_logp_grad, _native._ptr(self.Y), _native._ptr(self.packed), self.n,
+                self.d, self.k, _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative),
+                _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class MultivariateNormalTriL(FusedLogLikelihood):
@@ -274,13 +281,19 @@ class MultivariateNormalTriL(FusedLogLikelihood):
         self.n, self.d = self.Y.shape
         self.parameterisation = int(parameterisation)
         self.n_params = self.d + self.d * self.d
+        self.packed = _native.gmm_fullcov_pack(self.Y) if self.n > 0 else None
 
     def _call(self, theta, logp, grad, relative=False):
         c = theta.shape[0]
         buf = self.ws.get(_native.workspace_bytes(self.family, self.n, c, d=self.d))
-        _launch(_native.lib().bvi_mvn_tril_logp_grad, _native._ptr(self.Y), self.n, self.d, self.parameterisation,
-                _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative), _native._ptr(buf),
-                buf.numel(), _native._stream())
+        if self.packed is None:
+            _launch(_native.lib().bvi_mvn_tril_logp_grad, _native._ptr(self.Y), self.n, self.d, self.parameterisation,
+                    _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad), self._ref(relative),
+                    _native._ptr(buf), buf.numel(), _native._stream())
+            return
+        _launch(_native.lib().bvi_mvn_tril_packed_logp_grad, _native._ptr(self.Y), _native._ptr(self.packed), self.n,
+                self.d, self.parameterisation, _native._ptr(theta), c, _native._ptr(logp), _native._ptr(grad),
+                self._ref(relative), _native._ptr(buf), buf.numel(), _native._stream())
 
 
 class Posterior:

@@ -139,6 +139,50 @@ int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const flo
                                 logp_ref);
 }
 
+int bvi_gmm_fullcov_packed_bytes(int64_t n, int d, size_t* out_bytes) {
+  if (!out_bytes || n < 0) return BVI_ERR_ARG;
+  if (d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  *out_bytes = bvi_gmm_fullcov_packed_size(n, d);
+  return BVI_OK;
+}
+
+int bvi_gmm_fullcov_pack_scratch_bytes(int d, size_t* out_bytes) {
+  if (!out_bytes) return BVI_ERR_ARG;
+  if (d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  *out_bytes = bvi_gmm_fullcov_pack_scratch(d);
+  return BVI_OK;
+}
+
+int bvi_gmm_fullcov_pack(const float* Y, int64_t n, int d, void* packed, size_t packed_bytes, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if ((!Y && n > 0) || n < 0) return BVI_ERR_ARG;
+  if (d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  if (!packed || packed_bytes < bvi_gmm_fullcov_packed_size(n, d)) return BVI_ERR_WORKSPACE;
+  if (!ws || ws_bytes < bvi_gmm_fullcov_pack_scratch(d)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_gmm_fullcov_pack(Y, n, d, packed, ws, (hipStream_t)stream);
+}
+
+int bvi_gmm_fullcov_packed_logp_grad(const float* Y, const void* packed, int64_t n, int d, int k, const float* theta,
+                                     int n_chains, float* logp, float* grad, const double* logp_ref, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  if ((!Y && n > 0) || !packed || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (k < 1 || k > 16 || d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < bvi_ws_gmm_fullcov(n, n_chains, d, k)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_gmm_fullcov(Y, n, d, k, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream, logp_ref,
+                                packed);
+}
+
+int bvi_mvn_tril_packed_logp_grad(const float* Y, const void* packed, int64_t n, int d, int parameterisation,
+                                  const float* theta, int n_chains, float* logp, float* grad, const double* logp_ref,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if ((!Y && n > 0) || !packed || !theta || !logp || n < 0 || n_chains < 1) return BVI_ERR_ARG;
+  if (parameterisation != BVI_MVN_SCALE_TRIL && parameterisation != BVI_MVN_CHOL_PRECISION_SOLVE) return BVI_ERR_ARG;
+  if (d < 1 || d > 32) return BVI_ERR_UNSUPPORTED;
+  if (!ws || ws_bytes < bvi_ws_mvn_tril(n, n_chains, d)) return BVI_ERR_WORKSPACE;
+  return bvi_launch_mvn_tril(Y, n, d, parameterisation, theta, n_chains, logp, grad, (float*)ws, (hipStream_t)stream,
+                             logp_ref, packed);
+}
+
 int bvi_cluster_rows_scratch_bytes(int64_t n, int d, int n_centres, size_t* out_bytes) {
   if (!out_bytes || n < 0) return BVI_ERR_ARG;
   if (d < 1 || d > 32 || n_centres < 1 || n_centres > BVI_CLUSTER_MAX_CENTRES) return BVI_ERR_UNSUPPORTED;

@@ -51,10 +51,15 @@ int bvi_launch_linreg_packed(const void* packed, int64_t n, int d, const float* 
                              float* logp, float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
 
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
-                           float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
+                           float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr,
+                           const void* packed = nullptr);
+size_t bvi_gmm_fullcov_packed_size(int64_t n, int d);
+size_t bvi_gmm_fullcov_pack_scratch(int d);
+int bvi_launch_gmm_fullcov_pack(const float* Y, int64_t n, int d, void* packed, void* scratch, hipStream_t s);
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k);
 int bvi_launch_mvn_tril(const float* Y, int64_t n, int d, int mode, const float* theta, int c, float* logp,
-                        float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr);
+                        float* grad, float* ws, hipStream_t s, const double* logp_ref = nullptr,
+                        const void* packed = nullptr);
 size_t bvi_ws_mvn_tril(int64_t n, int c, int d);
 
 size_t bvi_ws_cluster_rows(int64_t n, int d, int m);

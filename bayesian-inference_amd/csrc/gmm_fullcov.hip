@@ -1726,10 +1726,73 @@ size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
   return (kStatFloats + prep + part + fullcov_tile_floats(n, c, k)) * sizeof(float);
 }
 
+// What of a call depends on the rows alone, computed once by bvi_launch_gmm_fullcov_pack: column centres and scales
+// (DP floats each), the tiles' and the tile groups' centres and radii, the two f16 planes of the rows (16-B aligned).
+namespace {
+struct PackedLayout {
+  size_t center, cscale, tstat, gstat, phi, plo, total;
+};
+PackedLayout packed_layout(int64_t n) {
+  const size_t ntiles = (size_t)((n + FT - 1) / FT), ngroups = (ntiles + 63) / 64;
+  PackedLayout L;
+  size_t o = 0;
+  L.center = o; o += DP * sizeof(float);
+  L.cscale = o; o += DP * sizeof(float);
+  L.tstat = o;  o += ntiles * (DP + 1) * sizeof(float);
+  L.gstat = o;  o += ngroups * (DP + 1) * sizeof(float);
+  o = (o + 255) & ~(size_t)255;
+  L.phi = o;    o += ntiles * FT * DP * 2;
+  L.plo = o;    o += ntiles * FT * DP * 2;
+  L.total = o + 256;
+  return L;
+}
+}  // namespace
+
+size_t bvi_gmm_fullcov_packed_size(int64_t n, int d) {
+  (void)d;
+  return packed_layout(n).total;
+}
+
+size_t bvi_gmm_fullcov_pack_scratch(int d) {
+  (void)d;
+  return kStatFloats * sizeof(float) + 256;
+}
+
+int bvi_launch_gmm_fullcov_pack(const float* Y, int64_t n, int d, void* packed, void* scratch, hipStream_t s) {
+  if (d < 1 || d > DP) return BVI_ERR_UNSUPPORTED;
+  if (((uintptr_t)scratch & 7) != 0 || ((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
+  const int64_t ntiles = (n + FT - 1) / FT, ngroups = (ntiles + 63) / 64;
+  const PackedLayout L = packed_layout(n);
+  unsigned char* pk = static_cast<unsigned char*>(packed);
+  float* ws = static_cast<float*>(scratch);
+  double* psum = (double*)ws;
+  float* pmin = ws + 2 * (size_t)kStatBlocks * DP;
+  float* pmax = pmin + (size_t)kStatBlocks * DP;
+  int* flag = reinterpret_cast<int*>(ws + kStatFloats);
+  float* center = reinterpret_cast<float*>(pk + L.center);
+  float* cscale = reinterpret_cast<float*>(pk + L.cscale);
+  float* tstat = reinterpret_cast<float*>(pk + L.tstat);
+  float* gstat = reinterpret_cast<float*>(pk + L.gstat);
+  const int sblocks = (int)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > kStatBlocks ? kStatBlocks : ntiles / 4));
+  hipError_t me = hipMemsetAsync(flag, 1, sizeof(int), s);            // "the planes are wanted"
+  if (me != hipSuccess) return (int)me;
+  hipLaunchKernelGGL(fullcov_tilestats, dim3(sblocks), dim3(256), 0, s, Y, n, d, ntiles, tstat, psum, pmin, pmax);
+  hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(1024), 0, s, (const double*)psum, (const float*)pmin,
+                     (const float*)pmax, sblocks, n, d, center, cscale);
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
+    const int pblocks = (int)(ntiles > 4096 ? 4096 : ntiles);
+    hipLaunchKernelGGL(fullcov_planes, dim3(pblocks), dim3(256), 0, s, Y, n, d, ntiles, (const float*)center,
+                       (const float*)cscale, (const int*)flag, pk + L.phi, pk + L.plo);
+  }
+  BVI_HIP_CHECK_LAUNCH();
+  return BVI_OK;
+}
+
 int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float* theta, int c, float* logp,
-                           float* grad, float* ws, hipStream_t s, const double* logp_ref) {
+                           float* grad, float* ws, hipStream_t s, const double* logp_ref, const void* packed) {
   if (d < 1 || d > DP || k < 1 || k > 16) return BVI_ERR_UNSUPPORTED;
-  if (((uintptr_t)ws & 7) != 0) return BVI_ERR_ARG;
+  if (((uintptr_t)ws & 7) != 0 || ((uintptr_t)packed & 15) != 0) return BVI_ERR_ARG;
   double* psum = (double*)ws;
   float* pmin = ws + 2 * (size_t)kStatBlocks * DP;
   float* pmax = pmin + (size_t)kStatBlocks * DP;
@@ -1759,6 +1822,16 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   any_single += (4 - (((uintptr_t)any_single >> 2) & 3)) & 3;            // 16-B aligned; the planes follow at + 16 B
   unsigned char* phi = reinterpret_cast<unsigned char*>(any_single + 4);
   unsigned char* plo = phi + (size_t)ntiles * FT * DP * 2;
+  if (packed) {             // the rows' own numbers come from the packed buffer; nothing of them is computed here
+    const PackedLayout L = packed_layout(n);
+    unsigned char* pk = const_cast<unsigned char*>(static_cast<const unsigned char*>(packed));
+    center = reinterpret_cast<float*>(pk + L.center);
+    cscale = reinterpret_cast<float*>(pk + L.cscale);
+    tstat = reinterpret_cast<float*>(pk + L.tstat);
+    gstat = reinterpret_cast<float*>(pk + L.gstat);
+    phi = pk + L.phi;
+    plo = pk + L.plo;
+  }
   // BVI_FULLCOV_F32=1 selects the exact-f32 kernel (v_mfma_f32_16x16x4_f32), kept as the reference the
   // f16-piece kernel is validated against
   static const bool use_f32 = getenv("BVI_FULLCOV_F32") && atoi(getenv("BVI_FULLCOV_F32")) != 0;
@@ -1788,18 +1861,21 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   } else {
     static const bool no_prune = getenv("BVI_FULLCOV_NO_PRUNE") && atoi(getenv("BVI_FULLCOV_NO_PRUNE")) != 0;
     const bool prune = k > 1 && ntiles > 0 && !no_prune;       // one component: nothing to leave out
-    const int sblocks = (int)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > kStatBlocks ? kStatBlocks : ntiles / 4));
-    hipLaunchKernelGGL(fullcov_tilestats, dim3(sblocks), dim3(256), 0, s, Y, n, d, ntiles,
-                       prune ? tstat : (float*)nullptr, psum, pmin, pmax);
-    hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(1024), 0, s, (const double*)psum, (const float*)pmin,
-                       (const float*)pmax, sblocks, n, d, center, cscale);
+    if (!packed) {
+      const int sblocks = (int)(ntiles / 4 < 1 ? 1 : (ntiles / 4 > kStatBlocks ? kStatBlocks : ntiles / 4));
+      hipLaunchKernelGGL(fullcov_tilestats, dim3(sblocks), dim3(256), 0, s, Y, n, d, ntiles,
+                         prune ? tstat : (float*)nullptr, psum, pmin, pmax);
+      hipLaunchKernelGGL(fullcov_colstats_final, dim3(1), dim3(1024), 0, s, (const double*)psum, (const float*)pmin,
+                         (const float*)pmax, sblocks, n, d, center, cscale);
+    }
     hipLaunchKernelGGL(fullcov_prepare, dim3(c * k), dim3(DP), 0, s, theta, c, k, d, (const float*)center, Ainv,
                        bvec, blo, cst);
     BVI_HIP_CHECK_LAUNCH();
     if (prune) {
       hipLaunchKernelGGL(fullcov_anorm, dim3(c * k), dim3(256), 0, s, theta, k, d, (const float*)center, (const float*)Ainv,
                          anorm, mudist, lnorm);
-      hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
+      if (!packed)
+        hipLaunchKernelGGL(fullcov_groupstats, dim3((unsigned)ngroups), dim3(64), 0, s, (const float*)tstat, ntiles, gstat);
       hipLaunchKernelGGL(fullcov_group_bounds, dim3((unsigned)bvi_ceil_div(ngroups, 64), c, k), dim3(64), 0, s,
                          (const float*)gstat, ngroups, k, (const float*)Ainv, (const float*)bvec, (const float*)cst,
                          (const float*)anorm, (const float*)center, gbounds);
@@ -1812,11 +1888,13 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
     const unsigned short* tmask_arg = prune ? tmask : nullptr;
     // one component: every tile is a single-component tile; no pruning otherwise: none is
     const bool lists_from_masks = prune || k == 1;
-    hipError_t me = hipMemsetAsync(any_single, 0, sizeof(int), s);
-    if (me != hipSuccess) return (int)me;
+    if (!packed) {
+      hipError_t me = hipMemsetAsync(any_single, 0, sizeof(int), s);
+      if (me != hipSuccess) return (int)me;
+    }
     hipLaunchKernelGGL(fullcov_tilelists, dim3(nblk, c), dim3(64), 0, s, lists_from_masks ? tmask_arg : (const unsigned short*)nullptr,
                        ntiles, lists_from_masks ? k : 16, cap, tlist, toff, any_single);
-    if (ntiles > 0) {
+    if (ntiles > 0 && !packed) {
       const int pblocks = (int)(ntiles > 4096 ? 4096 : ntiles);
       hipLaunchKernelGGL(fullcov_planes, dim3(pblocks), dim3(256), 0, s, Y, n, d, ntiles, (const float*)center,
                          (const float*)cscale, (const int*)any_single, phi, plo);

@@ -109,7 +109,7 @@ size_t bvi_ws_mvn_tril(int64_t n, int c, int d) {
 }
 
 int bvi_launch_mvn_tril(const float* Y, int64_t n, int d, int mode, const float* theta, int c, float* logp, float* grad,
-                        float* ws, hipStream_t s, const double* logp_ref) {
+                        float* ws, hipStream_t s, const double* logp_ref, const void* packed) {
   const size_t row = (size_t)(1 + d + d * d);
   unsigned char* base = reinterpret_cast<unsigned char*>(ws);
   float* kth = reinterpret_cast<float*>(base);
@@ -117,7 +117,7 @@ int bvi_launch_mvn_tril(const float* Y, int64_t n, int d, int mode, const float*
   double* sig = reinterpret_cast<double*>(base + align256(2 * (size_t)c * row * sizeof(float)));
   float* inner = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(sig) + align256((size_t)c * d * d * sizeof(double)));
   hipLaunchKernelGGL(mvn_prepare_kernel, dim3(c), dim3(64), 0, s, d, mode, theta, c, kth, sig);
-  const int st = bvi_launch_gmm_fullcov(Y, n, d, 1, kth, c, logp, grad ? kg : nullptr, inner, s, logp_ref);
+  const int st = bvi_launch_gmm_fullcov(Y, n, d, 1, kth, c, logp, grad ? kg : nullptr, inner, s, logp_ref, packed);
   if (st != BVI_OK) return st;
   if (grad) hipLaunchKernelGGL(mvn_grad_kernel, dim3(c), dim3(64), 0, s, d, mode, theta, sig, kg, c, grad);
   return (int)hipGetLastError();

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define BVI_VERSION 111
+#define BVI_VERSION 112
 
 #define BVI_OK 0
 #define BVI_ERR_ARG (-1)          /* NULL pointer, negative size, bad enum        */
@@ -229,6 +229,24 @@ int bvi_gmm1d_logp_grad(const float* y, int64_t n, int k, const float* theta, in
 int bvi_gmm_fullcov_logp_grad(const float* Y, int64_t n, int d, int k, const float* theta, int n_chains,
                               float* logp, float* grad, const double* logp_ref, void* ws, size_t ws_bytes,
                               void* stream);
+
+/* The part of bvi_gmm_fullcov_logp_grad / bvi_mvn_tril_logp_grad that depends on the rows alone, taken once per
+ * dataset: column centres and scales, the centre and radius of every 64-row tile and of every group of 64 tiles, and
+ * the rows' two f16 pieces (128 B per row).  The *_packed_logp_grad entry points take the rows AND the packed buffer
+ * (the kernel of the tiles several components reach reads the rows themselves) and skip four launches and one pass over
+ * the rows per call; results are bit-identical to the unpacked entry points'.  N = 125 000, D = 32, K = 16, 16 chains:
+ * 0.34 against 0.37 ms per leapfrog step of the device NUTS.  packed must be 16-byte aligned.  No counterpart in the reference (TFP keeps
+ * nothing between log_prob calls); the linear-regression analogue is bvi_linreg_pack. */
+int bvi_gmm_fullcov_packed_bytes(int64_t n, int d, size_t* out_bytes);
+int bvi_gmm_fullcov_pack_scratch_bytes(int d, size_t* out_bytes);
+int bvi_gmm_fullcov_pack(const float* Y, int64_t n, int d, void* packed, size_t packed_bytes, void* ws,
+                         size_t ws_bytes, void* stream);
+int bvi_gmm_fullcov_packed_logp_grad(const float* Y, const void* packed, int64_t n, int d, int k, const float* theta,
+                                     int n_chains, float* logp, float* grad, const double* logp_ref, void* ws,
+                                     size_t ws_bytes, void* stream);
+int bvi_mvn_tril_packed_logp_grad(const float* Y, const void* packed, int64_t n, int d, int parameterisation,
+                                  const float* theta, int n_chains, float* logp, float* grad, const double* logp_ref,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* One-time row order for bvi_gmm_fullcov_logp_grad: Y_out[n,d] = the rows of Y[n,d] stored so that rows lying close
  * together are neighbours (Lloyd's algorithm on n_centres <= BVI_CLUSTER_MAX_CENTRES centres started from rows at a

@@ -621,6 +621,36 @@ def test_gmm_fullcov(nat, ws, gpu_device, d, k, c, n):
     np.testing.assert_array_equal(lp2.cpu().numpy(), lp.cpu().numpy())
 
 
+@pytest.mark.parametrize('n,d,k', [(20000, 32, 16), (777, 5, 3), (40, 8, 2), (9000, 16, 1)])
+def test_gmm_fullcov_packed_equals_unpacked(nat, ws, gpu_device, n, d, k):
+    """bvi_gmm_fullcov_pack + bvi_gmm_fullcov_packed_logp_grad (the rows' own statistics and f16 pieces taken once)
+    against bvi_gmm_fullcov_logp_grad (taken per call): the same bits, with and without gradient, on rows stored
+    cluster by cluster and as drawn; and the same for the single multivariate normal."""
+    rng = np.random.default_rng(5 * n + d + k)
+    c = 5
+    true_mu = rng.integers(-12, 13, (k, d)).astype(np.float64)
+    Y = (true_mu[rng.integers(0, k, n)] + rng.normal(size=(n, d))).astype(np.float32)
+    w = rng.dirichlet(np.ones(k) * 5, c).astype(np.float32)
+    mu = (true_mu[None] + rng.normal(0, 0.2, (c, k, d))).astype(np.float32)
+    L = np.tril(rng.normal(size=(c, k, d, d)) * 0.05)
+    for i in range(d):
+        L[..., i, i] = rng.uniform(0.9, 1.3, (c, k))
+    theta = dev(np.concatenate([w, mu.reshape(c, -1), L.astype(np.float32).reshape(c, -1)], -1), gpu_device)
+    for rows in (dev(Y, gpu_device), nat.cluster_rows(dev(Y, gpu_device), 4 * k)):
+        packed = nat.gmm_fullcov_pack(rows)
+        lp, g = nat.gmm_fullcov_logp_grad(rows, theta, k, ws)
+        lp2, g2 = nat.gmm_fullcov_logp_grad(rows, theta, k, ws, packed=packed)
+        assert torch.equal(lp, lp2) and torch.equal(g, g2)
+        lpv, _ = nat.gmm_fullcov_logp_grad(rows, theta, k, ws, want_grad=False)
+        lpv2, _ = nat.gmm_fullcov_logp_grad(rows, theta, k, ws, want_grad=False, packed=packed)
+        assert torch.equal(lpv, lpv2)
+        if k == 1:
+            th1 = dev(np.concatenate([mu[:, 0], L[:, 0].astype(np.float32).reshape(c, -1)], -1), gpu_device)
+            a = nat.mvn_tril_logp_grad(rows, th1, nat.MVN_SCALE_TRIL, ws)
+            b = nat.mvn_tril_logp_grad(rows, th1, nat.MVN_SCALE_TRIL, ws, packed=packed)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize('n,d,m', [(50000, 32, 64), (12345, 5, 16), (4097, 1, 128), (100, 7, 128), (1, 3, 16),
                                    (300001, 16, 40)])
 def test_cluster_rows_is_a_stable_reproducible_grouping(nat, gpu_device, n, d, m):
