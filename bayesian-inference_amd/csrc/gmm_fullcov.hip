@@ -48,36 +48,53 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
   const float* mu = th + K + k * D;
   const float* L = th + K + K * D + k * D * D;
   __shared__ double A[DP][DP + 1];
-  __shared__ float Ls[DP][DP + 1];             // L staged once: the substitution below is one dependent chain per column
-  for (int i = 0; i < DP; ++i) {
-    A[i][j] = 0.0;
-    Ls[i][j] = (i < D && j < D) ? L[i * D + j] : 0.f;
-  }
+  __shared__ __attribute__((aligned(16))) double Ls[DP][DP];      // L, staged once; row i is read by every lane alike
+  __shared__ double invd[DP];
+#pragma unroll 8
+  for (int i = 0; i < DP; ++i) Ls[i][j] = (i < D && j < D) ? (double)L[i * D + j] : (i == j ? 1.0 : 0.0);
+  invd[j] = j < D ? 1.0 / (double)L[j * D + j] : 1.0;
   __syncthreads();
-  if (j < D) {
-    // column j of L^-1 by forward substitution
-    for (int i = j; i < D; ++i) {
+  {
+    // column j of L^-1 by forward substitution, the column in registers and every loop unrolled: one chain of
+    // D^2 / 2 dependent multiply-adds per thread, with nothing else on it (as a loop over LDS it carried two LDS
+    // round trips and a division per step: 39 us per call at D = 32).  Entries above the diagonal come out as the
+    // zeros they are, so all threads run the same code; the padding of L is the identity.
+    double a[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
       double s = (i == j) ? 1.0 : 0.0;
-      for (int m = j; m < i; ++m) s -= (double)Ls[i][m] * A[m][j];
-      A[i][j] = s / (double)Ls[i][i];
+#pragma unroll
+      for (int m = 0; m < i; m += 2) {
+        const double2 l2 = *reinterpret_cast<const double2*>(&Ls[i][m]);
+        s = fma(-l2.x, a[m], s);
+        if (m + 1 < i) s = fma(-l2.y, a[m + 1], s);
+      }
+      a[i] = s * invd[i];
+      A[i][j] = (i < D && j < D) ? a[i] : 0.0;
     }
   }
   __syncthreads();
   float* Ao = Ainv + ((int64_t)c * K + k) * DP * DP;
+#pragma unroll 8
   for (int i = 0; i < DP; ++i) Ao[i * DP + j] = (float)A[i][j];
+  // b = A (mu - center) with the A that the streaming kernel uses (rounded to f32): then u = A_f32 (y - mu) exactly,
+  // and the rounding of A multiplies the zero-mean (y - mu) instead of the common offset (mu - center)
+  __shared__ double dmu[DP];
+  dmu[j] = j < D ? (double)mu[j] - (center ? (double)center[j] : 0.0) : 0.0;
+  __syncthreads();
   double b = 0.0;
-  if (j < D)
-    // with the A that the streaming kernel uses (rounded to f32): then u = A_f32 (y - mu) exactly, and the
-    // rounding of A multiplies the zero-mean (y - mu) instead of the common offset (mu - center)
-    for (int m = 0; m < D; ++m) b += (double)(float)A[j][m] * ((double)mu[m] - (center ? (double)center[m] : 0.0));
+#pragma unroll 8
+  for (int m = 0; m < DP; ++m) b += (double)(float)A[j][m] * dmu[m];
   bvec[((int64_t)c * K + k) * DP + j] = (float)b;
   if (blo) blo[((int64_t)c * K + k) * DP + j] = (float)(b - (double)(float)b);
-  if (j == 0) {
-    double wsum = 0.0, ld = 0.0;
-    for (int m = 0; m < K; ++m) wsum += (double)th[m];
-    for (int m = 0; m < D; ++m) ld += log((double)Ls[m][m]);
-    cst[c * K + k] = (float)(log((double)th[k]) - log(wsum) - ld - 0.5 * D * BVI_LN2PI_D);
+  // constant of the component: every lane takes one logarithm and one weight, summed over the 32 lanes in a fixed order
+  double ld = j < D ? log(Ls[j][j]) : 0.0, wsum = j < K ? (double)th[j] : 0.0;
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {
+    ld += __shfl_xor(ld, off, 64);
+    wsum += __shfl_xor(wsum, off, 64);
   }
+  if (j == 0) cst[c * K + k] = (float)(log((double)th[k]) - log(wsum) - ld - 0.5 * D * BVI_LN2PI_D);
 }
 
 // For the far-component test (fullcov_bounds), per chain and component:
