@@ -1644,12 +1644,17 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
   double s1 = 0.0, s0 = 0.0, lp = 0.0;
   double col[RG];
   for (int r = 0; r < RG; ++r) col[r] = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    // a row block without tiles for the many-component kernel wrote nothing (the same for every thread)
-    if (toff && b < nb_dense) {
-      const int* so = toff + ((int64_t)c * nb_dense + b) * kListOffs;
-      if (so[kLists - 1] == so[kLists]) continue;
-    }
+  // a row block without tiles for the many-component kernel wrote nothing: its flags first, all at once (inside the
+  // loop each was a pair of dependent loads in front of the block's partial sums)
+  __shared__ unsigned char skip_dense[512];        // (fullcov_blocks gives at most 512 row blocks)
+  const int nsk = toff ? (nb_dense < 512 ? nb_dense : 512) : 0;
+  for (int b = threadIdx.x; b < nsk; b += blockDim.x) {
+    const int* so = toff + ((int64_t)c * nb_dense + b) * kListOffs;
+    skip_dense[b] = so[kLists - 1] == so[kLists] ? 1 : 0;
+  }
+  __syncthreads();
+  auto skipped = [&](int b) { return b < nsk && skip_dense[b] != 0; };
+  auto add_block = [&](int b) {
     const float* p = partials + ((int64_t)b * C + c) * stride + (int64_t)k * Q;
     if (grad) {                     // a value-only launch wrote the log-density partial only
       for (int r = 0; r < RG; ++r) col[r] += (double)p[1 + DP + (ig + 8 * r) * DP + j];
@@ -1659,6 +1664,46 @@ __global__ __launch_bounds__(8 * DP) void fullcov_finalize(const float* __restri
       if (grad) s0 += (double)p[0];
       if (k == 0) lp += (double)partials[((int64_t)b * C + c) * stride + (int64_t)K * Q];
     }
+  };
+  if (grad) {
+    // four blocks' loads in flight at a time; the sums keep the order b = 0, 1, 2, ...
+    int b = 0;
+    for (; b + 4 <= nb; b += 4) {
+      float v[4][RG], v1[4], v0[4], vl[4];
+      // every load unconditional (the addresses are inside the workspace whatever was written there), the selection
+      // afterwards: conditional loads would each sit in a branch of their own with a wait behind it
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = partials + ((int64_t)(b + u) * C + c) * stride + (int64_t)k * Q;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) v[u][r] = p[1 + DP + (ig + 8 * r) * DP + j];
+        v1[u] = p[1 + j];
+        v0[u] = p[0];
+        vl[u] = partials[((int64_t)(b + u) * C + c) * stride + (int64_t)K * Q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool on = !skipped(b + u);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) v[u][r] = on ? v[u][r] : 0.f;
+        v1[u] = (on && ig == 0) ? v1[u] : 0.f;
+        v0[u] = (on && threadIdx.x == 0) ? v0[u] : 0.f;
+        vl[u] = (on && threadIdx.x == 0 && k == 0) ? vl[u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) col[r] += (double)v[u][r];
+        s1 += (double)v1[u];
+        s0 += (double)v0[u];
+        lp += (double)vl[u];
+      }
+    }
+    for (; b < nb; ++b)
+      if (!skipped(b)) add_block(b);
+  } else {
+    for (int b = 0; b < nb; ++b)
+      if (!skipped(b)) add_block(b);
   }
   // the f16 kernel sums the rows' log-densities around a typical row's level (fullcov_row_level): back in double
   if (cst && threadIdx.x == 0 && k == 0) lp += (double)n * (double)fullcov_row_level(cst + (int64_t)c * K, K, D);
