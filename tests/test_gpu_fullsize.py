@@ -505,6 +505,36 @@ def test_fullcov_mixture_1m_rows_shards_add(nat, ws, gpu_device):
     assert float(err.abs().max()) <= 0.5, err.tolist()
 
 
+def test_fullcov_mixture_1m_rows_order_and_pack_do_not_matter(nat, ws, gpu_device):
+    """configs[3] shape at 1M rows: the rows as drawn through bvi_gmm_fullcov_logp_grad against the rows stored cluster by
+    cluster (bvi_cluster_rows) and packed (bvi_gmm_fullcov_pack) through bvi_gmm_fullcov_packed_logp_grad -- the
+    dense kernel against the pruned kernels on the same sums.  A sum over rows does not depend on their order: the
+    two must agree to float rounding of the sums, for well separated and for overlapping components, and the ordering
+    must be a permutation (every row once: compared through order-independent checksums of the rows)."""
+    n, d, k, c = 1_000_000, 32, 16, 6
+    for spread in (4.0, 0.8):                       # centres 4 widths apart per coordinate; 0.8: clusters overlap
+        g = torch.Generator(device=gpu_device); g.manual_seed(int(10 * spread))
+        centers = spread * torch.randn(k, d, generator=g, device=gpu_device)
+        Y = (centers[torch.randint(0, k, (n,), generator=g, device=gpu_device)]
+             + torch.randn(n, d, generator=g, device=gpu_device)).contiguous()
+        L = torch.eye(d, device=gpu_device)[None, None] * (1 + 0.1 * torch.rand(c, k, 1, 1, generator=g, device=gpu_device)) \
+            + 0.02 * torch.tril(torch.randn(c, k, d, d, generator=g, device=gpu_device), -1)
+        th = torch.cat([(1.0 / k) * (1 + 0.1 * torch.rand(c, k, generator=g, device=gpu_device)),
+                        (centers[None] + 0.05 * torch.randn(c, k, d, generator=g, device=gpu_device)).reshape(c, -1),
+                        L.reshape(c, -1)], -1).contiguous()
+        Yc, order = nat.cluster_rows(Y, 64, want_order=True)
+        assert torch.equal(torch.sort(order).values, torch.arange(n, device=gpu_device))
+        assert torch.equal(Yc.view(torch.int32).sum(0), Y.view(torch.int32).sum(0))      # integer sums: exact
+        packed = nat.gmm_fullcov_pack(Yc)
+        lp, gr = nat.gmm_fullcov_logp_grad(Y, th, k, ws)
+        lp2, gr2 = nat.gmm_fullcov_logp_grad(Yc, th, k, ws, packed=packed)
+        assert bool(torch.isfinite(lp2).all()) and bool(torch.isfinite(gr2).all())
+        _close(lp2, lp, lp.abs(), what='fullcov logp, rows reordered (spread %g)' % spread)
+        for lo, hi in ((0, k), (k, k + k * d), (k + k * d, th.shape[1])):
+            scale = gr[:, lo:hi].abs().max(-1, keepdim=True).values.double()
+            _close(gr2[:, lo:hi], gr[:, lo:hi], scale, rtol=3 * RTOL, what='fullcov grad, rows reordered (spread %g)' % spread)
+
+
 # ---- BASELINE.json configs[4]: ELBO gradients on the 10M x 64 regression with 256 Monte-Carlo samples ----
 def _vi_setup(r, gpu_device, rows=None):
     import collections
