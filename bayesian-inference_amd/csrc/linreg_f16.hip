@@ -911,31 +911,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---- pack: column statistics (two-stage, fixed order) then the split ----
-// stage 1: block b reduces rows b, b + nblk, ... : per column abs-max and sum (double), sum and abs-max of y.
-// Run twice: first on the columns as they are (shift == nullptr: the sums give the column means), then on the
-// centred columns x - shift (abs-max for the column scales; the sum of the exact differences).
+// stage 1: block b reduces rows b, b + nblk, ... : per column sum (double), minimum and maximum; sum, minimum and
+// maximum of y.  One pass gives everything the header needs: the column means are the shifts, and for the centred
+// columns x - shift the largest |x - shift| is taken at the column's minimum or maximum (rounding to float is
+// monotone) and their sum is sum(x) - n shift in double.  (The first version read the matrix a second time for
+// those two.)
 template <int D>
-__global__ __launch_bounds__(256) void f16_colstats_kernel(const float* __restrict__ X, const float* __restrict__ y,
-                                                           int64_t n, int dr, const float* __restrict__ shift,
-                                                           float* __restrict__ pmax, double* __restrict__ psum) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void f16_colstats_kernel(
+    const float* __restrict__ X, const float* __restrict__ y,
+                                                           int64_t n, int dr, float* __restrict__ pmax,
+                                                           double* __restrict__ psum) {
   // 256 threads = RL row lanes x D / 4 column groups: a thread owns four neighbouring columns (one 16-byte load per
   // row when the rows are D floats long and 16-byte aligned; element loads otherwise), four rows in flight
   constexpr int CGR = D / 4, RL = 256 / CGR;
   const int cg = threadIdx.x % CGR, rl = threadIdx.x / CGR, c0 = 4 * cg;
-  double m[4];
+  float mn[4], mx[4];                         // (NaN: kept out by fmaxf / fminf, found by the sums)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) m[j] = (shift && c0 + j < dr) ? (double)shift[c0 + j] : 0.0;
-  float amax[4] = {0.f, 0.f, 0.f, 0.f};
-  float yhi = -INFINITY, ylo = INFINITY;      // largest and smallest y (NaN: kept out by fmaxf / fminf, found by ysum)
+  for (int j = 0; j < 4; ++j) { mn[j] = INFINITY; mx[j] = -INFINITY; }
+  float yhi = -INFINITY, ylo = INFINITY;
   double sum[4] = {0.0, 0.0, 0.0, 0.0}, ysum = 0.0;
   const bool vec = dr == D && (((uintptr_t)X & 15) == 0);
   const int64_t stride = (int64_t)gridDim.x * RL;
   auto take = [&](const float (&v)[4], int64_t row) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const double d = c0 + j < dr ? (double)v[j] - m[j] : 0.0;
-      amax[j] = fmaxf(amax[j], fabsf((float)d));
-      sum[j] += d;
+      const float x = c0 + j < dr ? v[j] : 0.f;
+      mn[j] = fminf(mn[j], x);
+      mx[j] = fmaxf(mx[j], x);
+      sum[j] += (double)x;
     }
     if (cg == 0) {
       const float yv = y[row];
@@ -946,6 +949,7 @@ __global__ __launch_bounds__(256) void f16_colstats_kernel(const float* __restri
   };
   int64_t row = (int64_t)blockIdx.x * RL + rl;
   if (vec) {
+#pragma nounroll
     for (; row + 3 * stride < n; row += 4 * stride) {
       f32x4v q[4];
 #pragma unroll
@@ -957,25 +961,28 @@ __global__ __launch_bounds__(256) void f16_colstats_kernel(const float* __restri
       }
     }
   }
+#pragma nounroll
   for (; row < n; row += stride) {
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = c0 + j < dr ? X[row * dr + c0 + j] : 0.f;
     take(v, row);
   }
-  __shared__ float smax[256][4], syhi[256], sylo[256];
+  __shared__ float smn[256][4], smx[256][4], syhi[256], sylo[256];
   __shared__ double ssum[256][4], sy[256];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { smax[threadIdx.x][j] = amax[j]; ssum[threadIdx.x][j] = sum[j]; }
+  for (int j = 0; j < 4; ++j) { smn[threadIdx.x][j] = mn[j]; smx[threadIdx.x][j] = mx[j]; ssum[threadIdx.x][j] = sum[j]; }
   sy[threadIdx.x] = ysum;
   syhi[threadIdx.x] = yhi;
   sylo[threadIdx.x] = ylo;
   __syncthreads();
   if (rl == 0) {
-    for (int q = 1; q < RL; ++q) {
+#pragma nounroll
+    for (int q = 1; q < RL; ++q) {       // (unrolled, its LDS reads are all hoisted: 256 registers, one wave per SIMD)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        amax[j] = fmaxf(amax[j], smax[q * CGR + cg][j]);
+        mn[j] = fminf(mn[j], smn[q * CGR + cg][j]);
+        mx[j] = fmaxf(mx[j], smx[q * CGR + cg][j]);
         sum[j] += ssum[q * CGR + cg][j];
       }
       if (cg == 0) {
@@ -984,72 +991,75 @@ __global__ __launch_bounds__(256) void f16_colstats_kernel(const float* __restri
         ylo = fminf(ylo, sylo[q * CGR]);
       }
     }
+    // pmax[block]: column minima | column maxima | largest y | smallest y
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      pmax[(int64_t)blockIdx.x * (D + 2) + c0 + j] = amax[j];
+      pmax[(int64_t)blockIdx.x * (2 * D + 2) + c0 + j] = mn[j];
+      pmax[(int64_t)blockIdx.x * (2 * D + 2) + D + c0 + j] = mx[j];
       psum[(int64_t)blockIdx.x * (D + 1) + c0 + j] = sum[j];
     }
     if (cg == 0) {
-      pmax[(int64_t)blockIdx.x * (D + 2) + D] = yhi;
-      pmax[(int64_t)blockIdx.x * (D + 2) + D + 1] = ylo;
+      pmax[(int64_t)blockIdx.x * (2 * D + 2) + 2 * D] = yhi;
+      pmax[(int64_t)blockIdx.x * (2 * D + 2) + 2 * D + 1] = ylo;
       psum[(int64_t)blockIdx.x * (D + 1) + D] = ysum;
     }
   }
 }
 
-// CENTRED = false (after the first statistics pass): the shift vector (column means in f32, 0 where not finite) and
-// the statistics of y; CENTRED = true (after the second): the scales and sums of the centred columns
-template <int D, bool CENTRED>
+// The header from the partials of f16_colstats_kernel: the shift vector (column means in f32, 0 where not finite),
+// the scales and sums of the centred columns, the statistics of y.
+template <int D>
 __global__ __launch_bounds__(1024) void f16_header_kernel(const float* __restrict__ pmax, const double* __restrict__ psum,
                                                           int nblk, int64_t n, Header* __restrict__ hdr) {
   // 1024 threads = 16 slices x 64 columns: slice s folds the partials s, s + 16, ... of its column, then column
   // threads of slice 0 fold the 16 slices -- the same order every run (a single thread per column walking all
   // 1024 partials took half a millisecond)
-  __shared__ float fmx[16][64], fhi[16], flo[16];
+  __shared__ float fmn[16][64], fmx[16][64], fhi[16], flo[16];
   __shared__ double fsm[16][64], fys[16];
   const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  float amax = 0.f;
+  float cmn = INFINITY, cmx = -INFINITY;
   double sum = 0.0;
   if (col < D)
     for (int b = sl; b < nblk; b += 16) {
-      amax = fmaxf(amax, pmax[(int64_t)b * (D + 2) + col]);
+      cmn = fminf(cmn, pmax[(int64_t)b * (2 * D + 2) + col]);
+      cmx = fmaxf(cmx, pmax[(int64_t)b * (2 * D + 2) + D + col]);
       sum += psum[(int64_t)b * (D + 1) + col];
     }
-  fmx[sl][col] = amax;
+  fmn[sl][col] = cmn;
+  fmx[sl][col] = cmx;
   fsm[sl][col] = sum;
-  if (col == 0 && !CENTRED) {
+  if (col == 0) {
     double ys = 0.0;
     float yhi = -INFINITY, ylo = INFINITY;
     for (int b = sl; b < nblk; b += 16) {
       ys += psum[(int64_t)b * (D + 1) + D];
-      yhi = fmaxf(yhi, pmax[(int64_t)b * (D + 2) + D]);
-      ylo = fminf(ylo, pmax[(int64_t)b * (D + 2) + D + 1]);
+      yhi = fmaxf(yhi, pmax[(int64_t)b * (2 * D + 2) + 2 * D]);
+      ylo = fminf(ylo, pmax[(int64_t)b * (2 * D + 2) + 2 * D + 1]);
     }
     fys[sl] = ys; fhi[sl] = yhi; flo[sl] = ylo;
   }
   __syncthreads();
   if (sl != 0) return;
   for (int q = 1; q < 16; ++q) {
-    amax = fmaxf(amax, fmx[q][col]);
+    cmn = fminf(cmn, fmn[q][col]);
+    cmx = fmaxf(cmx, fmx[q][col]);
     sum += fsm[q][col];
   }
   if (col < D) {
-    if (CENTRED) {
-      hdr->colscale[col] = amax > 0.f ? col_scale(amax) : 0.f;   // 0 marks an all-zero (here: constant) column
-      hdr->colsum[col] = sum;
-    } else {
-      const float mean = n > 0 ? (float)(sum / (double)n) : 0.f;
-      hdr->shift[col] = isfinite(mean) ? mean : 0.f;
-    }
+    const float mean = n > 0 ? (float)(sum / (double)n) : 0.f;
+    const float shift = isfinite(mean) ? mean : 0.f;
+    // largest |x - shift| of the column, rounded as the plane's values are: at one of its two ends
+    const float amax = n > 0 ? fmaxf(fabsf((float)((double)cmx - (double)shift)), fabsf((float)((double)cmn - (double)shift)))
+                             : 0.f;
+    hdr->shift[col] = shift;
+    hdr->colscale[col] = amax > 0.f ? col_scale(amax) : 0.f;   // 0 marks an all-zero (here: constant) column
+    hdr->colsum[col] = sum - (double)n * (double)shift;         // sum of the centred column
   } else {
-    if (CENTRED) {
-      hdr->colscale[col] = 0.f;
-      hdr->colsum[col] = 0.0;
-    } else {
-      hdr->shift[col] = 0.f;
-    }
+    hdr->shift[col] = 0.f;
+    hdr->colscale[col] = 0.f;
+    hdr->colsum[col] = 0.0;
   }
-  if (col == 0 && !CENTRED) {
+  if (col == 0) {
     double ys = 0.0;
     float yhi = -INFINITY, ylo = INFINITY;
     for (int q = 0; q < 16; ++q) {
@@ -1529,7 +1539,7 @@ size_t bvi_linreg_f16_packed_size(int64_t n, int d) {
 // scratch for the column statistics of the pack step (bytes)
 size_t bvi_linreg_f16_pack_scratch(int d) {
   const int dp = plane_cols(d);
-  return (size_t)kStatBlocks * (dp + 2) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
+  return (size_t)kStatBlocks * (2 * dp + 2) * sizeof(float) + (size_t)kStatBlocks * (dp + 1) * sizeof(double) +
          (size_t)kGramBlocks * kSumStride * sizeof(double) + 16;
 }
 
@@ -1545,30 +1555,16 @@ int bvi_launch_linreg_f16_pack(const float* X, const float* y, int64_t n, int d,
   float* pmax = (float*)(gpart + (size_t)kGramBlocks * kSumStride);
   double* gram = (double*)((unsigned char*)packed + kGramOffset);
   double* low = (double*)((unsigned char*)packed + kLowOffset);
-  const int64_t total = np * (dp / 8);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  if (blocks < 1) blocks = 1;
   if (dp == 64) {
-    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
-                       pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<64, false>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
-                       (const double*)psum, kStatBlocks, n, (Header*)packed);
-    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d,
-                       (const float*)((const Header*)packed)->shift, pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<64, true>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
-                       (const double*)psum, kStatBlocks, n, (Header*)packed);
+    hipLaunchKernelGGL(f16_colstats_kernel<64>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
+    hipLaunchKernelGGL(f16_header_kernel<64>, dim3(1), dim3(1024), 0, s, (const float*)pmax, (const double*)psum,
+                       kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_sums_kernel<64>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed,
                        gpart);
   } else {
-    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, (const float*)nullptr,
-                       pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<32, false>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
-                       (const double*)psum, kStatBlocks, n, (Header*)packed);
-    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d,
-                       (const float*)((const Header*)packed)->shift, pmax, psum);
-    hipLaunchKernelGGL((f16_header_kernel<32, true>), dim3(1), dim3(1024), 0, s, (const float*)pmax,
-                       (const double*)psum, kStatBlocks, n, (Header*)packed);
+    hipLaunchKernelGGL(f16_colstats_kernel<32>, dim3(kStatBlocks), dim3(256), 0, s, X, y, n, d, pmax, psum);
+    hipLaunchKernelGGL(f16_header_kernel<32>, dim3(1), dim3(1024), 0, s, (const float*)pmax, (const double*)psum,
+                       kStatBlocks, n, (Header*)packed);
     hipLaunchKernelGGL(f16_pack_sums_kernel<32>, dim3(kGramBlocks), dim3(256), 0, s, X, y, n, d, np, (unsigned char*)packed,
                        gpart);
   }
