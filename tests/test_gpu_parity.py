@@ -762,6 +762,50 @@ def test_gmm_fullcov_tile_kinds(nat, ws, gpu_device, d, k, n, spread, pair_gap):
     assert np.array_equal(lp2.cpu().numpy()[:3], lp[:3]) and np.array_equal(g2.cpu().numpy()[:3], g[:3])
 
 
+@pytest.mark.parametrize('d,k', [(32, 8), (6, 4)])
+def test_gmm_fullcov_bounds_hold_for_hard_scale_matrices(nat, ws, gpu_device, d, k):
+    """What the per-tile bounds must not get wrong, against the float64 oracle on rows stored cluster by cluster and
+    packed: scale matrices with condition number ~1000 (a bound from the distance to the mean alone overshoots along
+    the long axis: the component must stay wherever it matters), one broad component that covers every cluster (it is
+    within reach of every tile and carries a few percent of every row), a component of weight 1e-30 (out of reach
+    everywhere but finite), strongly correlated factors, and chains whose means sit between clusters."""
+    rng = np.random.default_rng(77 * d + k)
+    n, c = 7000, 5
+    true_mu = rng.integers(-15, 16, (k, d)).astype(np.float64)
+    comp = rng.integers(0, k, n)
+    Y = (true_mu[comp] + rng.normal(size=(n, d))).astype(np.float32)
+    w = rng.dirichlet(np.ones(k) * 5, c)
+    mu = true_mu[None] + rng.normal(0, 0.1, (c, k, d))
+    L = np.zeros((c, k, d, d))
+    for ci in range(c):
+        for kk in range(k):
+            q, _ = np.linalg.qr(rng.normal(size=(d, d)))
+            ev = np.ones(d)
+            if ci == 0:
+                ev = np.geomspace(0.05, 50.0, d)              # condition number 1000 in every component
+            elif ci == 1 and kk == 0:
+                ev = np.full(d, 20.0)                         # one broad component over everything
+            elif ci == 2:
+                ev = rng.uniform(0.5, 2.0, d)
+                ev[0] = 30.0                                  # one long axis per component
+            cov = (q * ev ** 2) @ q.T
+            L[ci, kk] = np.linalg.cholesky(cov)
+    w[3, 1] = 1e-30                                           # chain 3: a component of (almost) no weight
+    mu[4] = 0.5 * (true_mu + np.roll(true_mu, 1, 0))[None]    # chain 4: every mean half way between two clusters
+    w, mu, L = w.astype(np.float32), mu.astype(np.float32), L.astype(np.float32)
+    theta = np.concatenate([w, mu.reshape(c, -1), L.reshape(c, -1)], -1)
+    ref_lp, (gw, gmu, gL) = cf.gmm_fullcov(Y, w, mu, L)
+    ref_g = np.concatenate([gw, gmu.reshape(c, -1), gL.reshape(c, -1)], -1)
+    rows = nat.cluster_rows(dev(Y, gpu_device), 4 * k)
+    packed = nat.gmm_fullcov_pack(rows)
+    lp, g = nat.gmm_fullcov_logp_grad(rows, dev(theta, gpu_device), k, ws, packed=packed)
+    assert_logp_close(lp.cpu().numpy(), ref_lp)
+    assert_grad_close(g.cpu().numpy(), ref_g, term_scale=np.full_like(ref_g, 3.0 * n))
+    lp0, g0 = nat.gmm_fullcov_logp_grad(dev(Y, gpu_device), dev(theta, gpu_device), k, ws)      # rows as drawn, unpacked
+    assert_logp_close(lp0.cpu().numpy(), ref_lp)
+    assert_grad_close(g0.cpu().numpy(), ref_g, term_scale=np.full_like(ref_g, 3.0 * n))
+
+
 def test_gmm_fullcov_random_shapes(nat, ws, gpu_device):
     """Thirty random shapes (K 1 .. 16, D 1 .. 32, 1 .. 2500 rows, 1 .. 5 chains; separated, overlapping or coincident
     components; rows as drawn or cluster by cluster) against the float64 oracle: whatever mix of tile kinds the masks
