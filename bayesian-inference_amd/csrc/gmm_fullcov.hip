@@ -98,14 +98,18 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
 }
 
 // For the far-component test (fullcov_bounds), per chain and component:
-//   anorm  = an upper bound of the spectral norm of A: |A|_2^2 = lambda_max(M), M = A^T A, and lambda_max(M)^8 =
-//            lambda_max(M^8) <= |M^8|_F, which is within DP^(1/16) = 1.24 of it -- three squarings in float, each
-//            normalised by its largest entry;
-//   mudist = |mu_k - center|;
-//   lnorm  = an upper bound of the spectral norm of L = A^-1 (so that |A v| >= |v| / lnorm): sqrt(|L|_1 |L|_inf),
-//            the largest column sum times the largest row sum of |L| -- looser than anorm's, and enough for what it
-//            is used for (telling components many widths away from a tile apart from the one the tile belongs to).
-// One workgroup of 256 threads per (chain, component): thread (rg, j) owns rows rg, rg + 8, ... of column j.
+//   anorm  = an upper bound of the spectral norm of A: |A|_2^2 = lambda_max(M), M = A^T A, and lambda_max(M)^(2^p) =
+//            lambda_max(M^(2^p)) <= |M^(2^p)|_F, which is within DP^(1/2) of it -- p = kNormSquarings squarings in
+//            float, each normalised by its largest entry: the bound on |A|_2 is within DP^(1/2^(p+2)) = 1.4 % of the
+//            norm (three squarings left 11 %, which goes straight into the radius term of every tile's bounds);
+//   lnorm  = the same for L = A^-1 (so that |A v| >= |v| / lnorm);
+//   mudist = |mu_k - center|.
+// One workgroup of 256 threads per (chain, component): thread (rg, j) owns rows rg, rg + 8, ... of column j; the two
+// matrices go through the same steps side by side.
+#ifndef FC_NSQ
+#define FC_NSQ 6
+#endif
+constexpr int kNormSquarings = FC_NSQ;
 __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ theta, int K, int D,
                                                      const float* __restrict__ center, const float* __restrict__ Ainv,
                                                      float* __restrict__ anorm, float* __restrict__ mudist,
@@ -113,71 +117,84 @@ __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ t
   const int c = blockIdx.x / K, k = blockIdx.x % K, tid = threadIdx.x, j = tid & (DP - 1), rg = tid / DP;
   const int P = K + K * D + K * D * D;
   const float* mu = theta + (int64_t)c * P + K + k * D;
-  __shared__ float Af[DP][DP + 1], Mq[2][DP][DP + 1];
-  __shared__ float red[4];
-  auto block_reduce = [&](float v, bool take_max) {     // NaN-blind maxima on purpose: the final sum carries a NaN through
+  __shared__ float Af[2][DP][DP + 1], Mq[2][2][DP][DP + 1];       // [A | L], [A | L][buffer]
+  __shared__ float red[2][4];
+  // sums or maxima of two values over the workgroup (NaN-blind maxima on purpose: the final sums carry a NaN through)
+  auto block_reduce2 = [&](float& v0, float& v1, bool take_max) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      const float o = __shfl_xor(v, off, 64);
-      v = take_max ? fmaxf(v, o) : v + o;
+      const float o0 = __shfl_xor(v0, off, 64), o1 = __shfl_xor(v1, off, 64);
+      v0 = take_max ? fmaxf(v0, o0) : v0 + o0;
+      v1 = take_max ? fmaxf(v1, o1) : v1 + o1;
     }
     __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
+    if ((tid & 63) == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; }
     __syncthreads();
-    return take_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+    v0 = take_max ? fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))
+                  : (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    v1 = take_max ? fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]))
+                  : (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   };
   const float* Ak = Ainv + ((int64_t)c * K + k) * DP * DP;
-  for (int i = rg; i < DP; i += 8) Af[i][j] = Ak[i * DP + j];
-  const float dmu = (rg == 0 && j < D) ? mu[j] - center[j] : 0.f;
-  const float md2 = block_reduce(dmu * dmu, false);     // (its barriers also publish Af)
-  if (tid == 0) mudist[c * K + k] = sqrtf(md2);
-  {
-    const float* L = theta + (int64_t)c * P + K + K * D + (int64_t)k * D * D;
-    float rs = 0.f, csm = 0.f;                          // row j and column j of |L| (lower triangle)
-    if (rg == 0 && j < D) {
-      for (int m = 0; m <= j; ++m) rs += fabsf(L[j * D + m]);
-      for (int i = j; i < D; ++i) csm += fabsf(L[i * D + j]);
-    }
-    const float rmax = block_reduce(rs, true), cmx = block_reduce(csm, true);
-    // (a NaN entry is lost in the maxima: the sum below brings it back)
-    const float chk = block_reduce(rg == 0 && j < D ? rs - rs : 0.f, false);
-    if (tid == 0) lnorm[c * K + k] = sqrtf(rmax * cmx) * 1.0001f + chk;
-  }
-  float cmax = 0.f;
+  const float* L = theta + (int64_t)c * P + K + K * D + (int64_t)k * D * D;
   for (int i = rg; i < DP; i += 8) {
-    float v = 0.f;
-#pragma unroll
-    for (int m = 0; m < DP; ++m) v = fmaf(Af[m][i], Af[m][j], v);
-    Mq[0][i][j] = v;
-    cmax = fmaxf(cmax, fabsf(v));
+    Af[0][i][j] = Ak[i * DP + j];
+    Af[1][i][j] = (i < D && j <= i) ? L[i * D + j] : 0.f;          // the lower triangle, as the model reads it
   }
-  float scale[4];
-  scale[0] = block_reduce(cmax, true);
-  int cur = 0;
-  for (int sq = 0; sq < 3; ++sq) {
-    const float inv = scale[sq] > 0.f ? 1.f / scale[sq] : 0.f;
-    cmax = 0.f;
-    for (int i = rg; i < DP; i += 8) {
+  float md2 = (rg == 0 && j < D) ? (mu[j] - center[j]) * (mu[j] - center[j]) : 0.f, unused = 0.f;
+  block_reduce2(md2, unused, false);                                // (its barriers also publish Af)
+  if (tid == 0) mudist[c * K + k] = sqrtf(md2);
+  float cmax[2] = {0.f, 0.f};
+  for (int i = rg; i < DP; i += 8) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
       float v = 0.f;
 #pragma unroll
-      for (int m = 0; m < DP; ++m) v = fmaf(Mq[cur][i][m] * inv, Mq[cur][m][j] * inv, v);
-      Mq[cur ^ 1][i][j] = v;
-      cmax = fmaxf(cmax, fabsf(v));
+      for (int m = 0; m < DP; ++m) v = fmaf(Af[q][m][i], Af[q][m][j], v);
+      Mq[q][0][i][j] = v;
+      cmax[q] = fmaxf(cmax[q], fabsf(v));
     }
-    scale[sq + 1] = block_reduce(cmax, true);
+  }
+  float scale[2][kNormSquarings + 1];
+  block_reduce2(cmax[0], cmax[1], true);
+  scale[0][0] = cmax[0];
+  scale[1][0] = cmax[1];
+  int cur = 0;
+#pragma unroll
+  for (int sq = 0; sq < kNormSquarings; ++sq) {
+    cmax[0] = cmax[1] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float inv = scale[q][sq] > 0.f ? 1.f / scale[q][sq] : 0.f;
+      for (int i = rg; i < DP; i += 8) {
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < DP; ++m) v = fmaf(Mq[q][cur][i][m] * inv, Mq[q][cur][m][j] * inv, v);
+        Mq[q][cur ^ 1][i][j] = v;
+        cmax[q] = fmaxf(cmax[q], fabsf(v));
+      }
+    }
+    block_reduce2(cmax[0], cmax[1], true);
+    scale[0][sq + 1] = cmax[0];
+    scale[1][sq + 1] = cmax[1];
     cur ^= 1;
   }
-  float fro = 0.f;
-  const float inv = scale[3] > 0.f ? 1.f / scale[3] : 0.f;
-  for (int i = rg; i < DP; i += 8) fro = fmaf(Mq[cur][i][j] * inv, Mq[cur][i][j] * inv, fro);
-  const float f = block_reduce(fro, false);
+  float fro[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float inv = scale[q][kNormSquarings] > 0.f ? 1.f / scale[q][kNormSquarings] : 0.f;
+    for (int i = rg; i < DP; i += 8) fro[q] = fmaf(Mq[q][cur][i][j] * inv, Mq[q][cur][i][j] * inv, fro[q]);
+  }
+  block_reduce2(fro[0], fro[1], false);
   if (tid == 0) {
-    // lambda(M) <= s0 sqrt(s1 sqrt(s2 sqrt(s3 |N3|_F)))
-    float lam = scale[3] * sqrtf(f);
-    lam = scale[2] * sqrtf(lam);
-    lam = scale[1] * sqrtf(lam);
-    lam = scale[0] * sqrtf(lam);
-    anorm[c * K + k] = sqrtf(lam) * 1.0001f;
+    // lambda(M) <= s0 sqrt(s1 sqrt(s2 ... sqrt(s_p |N_p|_F)))
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float lam = scale[q][kNormSquarings] * sqrtf(fro[q]);
+#pragma unroll
+      for (int sq = kNormSquarings - 1; sq >= 0; --sq) lam = scale[q][sq] * sqrtf(lam);
+      (q == 0 ? anorm : lnorm)[c * K + k] = sqrtf(lam) * 1.0001f;
+    }
   }
 }
 
@@ -387,7 +404,8 @@ __global__ __launch_bounds__(64) void fullcov_group_bounds(const float* __restri
 //      |m - mu_k| / lnorm_k <= |u_k(m)| <= anorm_k |m - mu_k|.  A tile in the middle of its cluster is left with that
 //      cluster's component; a tile that straddles two clusters (one per boundary) keeps many, and stays as it is;
 //   3. |u_k(m)| itself (D^2 / 2 multiplications, A_k through LDS, every lane reading the same element), only when
-//      some tile of the wave is left with two or three components by step 2: overlapping clusters.
+//      some tile of the wave is left with two to six components by step 2: neighbouring or overlapping clusters.
+constexpr int kRefineMax = 6;      // step 3 runs for tiles step 2 leaves with 2 .. kRefineMax components
 __global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ tstat, int64_t ntiles, int K, int D,
                                                       const float* __restrict__ theta,
                                                       const float* __restrict__ Ainv, const float* __restrict__ bvec,
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(64) void fullcov_bounds(const float* __restrict__ t
       if (k < K && ((sup >> k) & 1u) && !(ubc[k] < th2)) m2 |= 1u << k;
     if (!keeps_all) mask = m2;
     // 3.
-    const bool refine = tv && !keeps_all && __builtin_popcount(m2) >= 2 && __builtin_popcount(m2) <= 3 &&
+    const bool refine = tv && !keeps_all && __builtin_popcount(m2) >= 2 && __builtin_popcount(m2) <= kRefineMax &&
                         (m2 & ~open) == 0;
     unsigned supx = 0;
     for (int k = 0; k < K; ++k)
@@ -854,67 +872,109 @@ __global__ __launch_bounds__(1024) void fullcov_colstats_final(const double* __r
 // R = 8, 4 or 2 waves (every wave then has work), otherwise to one.
 __host__ __device__ __forceinline__ int fullcov_replicas(int K) { return K <= 1 ? 8 : K <= 2 ? 4 : K <= 4 ? 2 : 1; }
 
-// Sorts the tiles of every (chain, row block) into 2 FW + 1 lists, ascending inside each: list w + FW q (w < FW,
-// q < 2) = the tiles that ONE component reaches, namely component (w % K8) + FW q, and that wave w of
-// fullcov_single_kernel takes (with replicated components the replicas take turns); list 2 FW = the tiles several
-// components reach (fullcov_f16_kernel).  tlist[(chain, block)][cap] holds the lists back to back,
-// toff[(chain, block)][kListOffs] their starts, the end, and one flag: whether the masks leave out at least an eighth
-// of the (tile, component) pairs of the last list -- then the instantiation of fullcov_f16_kernel that looks at the
-// masks takes this (chain, block), otherwise the one without that code (which is a tenth faster on full masks).  tmask == nullptr: every tile is reached by all K
-// components.  One wave per (chain, block), 64 tiles per step, positions from ballots.
-constexpr int kLists = 2 * FW + 1, kListOffs = kLists + 2;   // starts, end, and the mode of the last list
+// Sorts the tiles of every (chain, row block) into 2 FW + 1 lists: list w + FW q (w < FW, q < 2) = what wave w of
+// fullcov_single_kernel does for component (w % K8) + FW q (with replicated components the replicas take turns):
+// first the tiles that component alone reaches, then -- once per component -- the tiles that two or three components
+// reach (kFewMax; `both` false, a value-only call: under their first component only, the one that adds their
+// log-densities); list 2 FW = the tiles more components reach, or none (fullcov_f16_kernel).  An entry is (tile,
+// mask of the components that reach it).  tlist[(chain, block)][cap] holds the lists back to back,
+// toff[(chain, block)][kListOffs]: the lists' starts, the end, one flag -- whether the masks leave out at least an
+// eighth of the (tile, component) pairs of the last list: then the instantiation of fullcov_f16_kernel that looks at
+// the masks takes this (chain, block), otherwise the one without that code (which is a tenth faster on full masks) --
+// and, for the first 2 FW lists, where their second part starts.  tmask == nullptr: every tile is reached by all K
+// components.  One wave per (chain, block), 64 tiles per step, positions from ballots: inside each part of a list the
+// order is by step, then by the component's place in the tile's mask, then by tile -- the same on every run.
+constexpr int kLists = 2 * FW + 1, kListOffs = kLists + 2 + 2 * FW;
+constexpr int kFewOff = kLists + 2;                  // toff[kFewOff + j]: start of the second part of list j
+constexpr int kFewMax = 3;
 __global__ __launch_bounds__(64) void fullcov_tilelists(const unsigned short* __restrict__ tmask, int64_t ntiles, int K,
-                                                        int cap, int* __restrict__ tlist, int* __restrict__ toff,
-                                                        int* __restrict__ any_single) {
+                                                        int cap, int2* __restrict__ tlist, int* __restrict__ toff,
+                                                        int* __restrict__ any_single, int both) {
   const int c = blockIdx.y, b = blockIdx.x, nb = gridDim.x, lane = threadIdx.x;
   const int R = fullcov_replicas(K), K8 = FW / R;
   const unsigned kmask = (1u << K) - 1u;
-  int* seg = tlist + ((int64_t)c * nb + b) * cap;
+  int2* seg = tlist + ((int64_t)c * nb + b) * cap;
   int* so = toff + ((int64_t)c * nb + b) * kListOffs;
   const int cnt_tiles = b < ntiles ? (int)((ntiles - b + nb - 1) / nb) : 0;
   int saved = 0;                                      // (tile, component) pairs of the last list the masks leave out
-  auto classify = [&](int i, int& entry) -> int {     // i-th tile of this block; returns its list, -1 past the end
-    if (i >= cnt_tiles) return -1;
-    const int64_t t = b + (int64_t)i * nb;
-    const unsigned m = tmask ? (tmask[(int64_t)c * ntiles + t] & kmask) : kmask;
-    entry = (int)t;
-    if (__builtin_popcount(m) != 1) {
-      saved += K - __builtin_popcount(m);
-      return 2 * FW;
-    }
-    const int k = __builtin_ctz(m);
-    return (k % FW) % K8 + K8 * (i % R) + (k >= FW ? FW : 0);
+  auto mask_of = [&](int i) -> unsigned {             // i-th tile of this block (0 past the end: no list)
+    if (i >= cnt_tiles) return 0u;
+    return tmask ? (tmask[(int64_t)c * ntiles + b + (int64_t)i * nb] & kmask) : kmask;
   };
-  int count[kLists];
+  auto list_of = [&](int i, int k) { return (k % FW) % K8 + K8 * (i % R) + (k >= FW ? FW : 0); };
+  // first part: the list of a tile one component reaches, 2 FW for a tile of the last list, -1: neither
+  auto classify = [&](int i, unsigned m) -> int {
+    if (i >= cnt_tiles) return -1;
+    const int pc = __builtin_popcount(m);
+    if (pc == 0 || pc > kFewMax) return 2 * FW;
+    return pc == 1 ? list_of(i, __builtin_ctz(m)) : -1;
+  };
+  // second part: the list of slot s (the s-th component of its mask) of a tile two or three components reach
+  auto classify_few = [&](int i, unsigned m, int s) -> int {
+    if (i >= cnt_tiles) return -1;
+    const int pc = __builtin_popcount(m);
+    if (pc < 2 || pc > kFewMax || s >= pc || (s > 0 && !both)) return -1;
+    unsigned r = m;
+    for (int q = 0; q < s; ++q) r &= r - 1;
+    return list_of(i, __builtin_ctz(r));
+  };
+  int count[kLists], countf[2 * FW];
 #pragma unroll
   for (int j = 0; j < kLists; ++j) count[j] = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * FW; ++j) countf[j] = 0;
   for (int i0 = 0; i0 < cnt_tiles; i0 += 64) {
-    int e;
-    const int cl = classify(i0 + lane, e);
+    const unsigned m = mask_of(i0 + lane);
+    const int pc = __builtin_popcount(m);
+    if (i0 + lane < cnt_tiles && (pc == 0 || pc > kFewMax)) saved += K - pc;
+    const int cl = classify(i0 + lane, m);
 #pragma unroll
     for (int j = 0; j < kLists; ++j) count[j] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cl == j));
-  }
-  int start[kLists], run = 0;
+    for (int s = 0; s < kFewMax; ++s) {
+      if (__builtin_amdgcn_ballot_w64(pc > s && pc >= 2 && pc <= kFewMax) == 0) break;      // (the same in every lane)
+      const int cf = classify_few(i0 + lane, m, s);
 #pragma unroll
-  for (int j = 0; j < kLists; ++j) { start[j] = run; run += count[j]; }
+      for (int j = 0; j < 2 * FW; ++j) countf[j] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(cf == j));
+    }
+  }
+  int start[kLists], startf[2 * FW], run = 0;
+#pragma unroll
+  for (int j = 0; j < kLists; ++j) {
+    start[j] = run;
+    run += count[j];
+    if (j < 2 * FW) { startf[j] = run; run += countf[j]; }
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) saved += __shfl_xor(saved, off, 64);
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < kLists; ++j) so[j] = start[j];
+#pragma unroll
+    for (int j = 0; j < 2 * FW; ++j) so[kFewOff + j] = startf[j];
     so[kLists] = run;
     so[kLists + 1] = (tmask != nullptr && saved * 8 >= K * count[kLists - 1] && saved > 0) ? 1 : 0;
     if (start[kLists - 1] > 0) *any_single = 1;       // some tile goes to fullcov_single_kernel: it needs the planes
   }
-  saved = 0;
   for (int i0 = 0; i0 < cnt_tiles; i0 += 64) {
-    int e = 0;
-    const int cl = classify(i0 + lane, e);
+    const unsigned m = mask_of(i0 + lane);
+    const int pc = __builtin_popcount(m);
+    const int2 e = make_int2((int)(b + (int64_t)(i0 + lane) * nb), (int)m);
+    const int cl = classify(i0 + lane, m);
 #pragma unroll
     for (int j = 0; j < kLists; ++j) {
       const unsigned long long bal = __builtin_amdgcn_ballot_w64(cl == j);
       if (cl == j) seg[start[j] + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = e;
       start[j] += __builtin_popcountll(bal);
+    }
+    for (int s = 0; s < kFewMax; ++s) {
+      if (__builtin_amdgcn_ballot_w64(pc > s && pc >= 2 && pc <= kFewMax) == 0) break;
+      const int cf = classify_few(i0 + lane, m, s);
+#pragma unroll
+      for (int j = 0; j < 2 * FW; ++j) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(cf == j);
+        if (cf == j) seg[startf[j] + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = e;
+        startf[j] += __builtin_popcountll(bal);
+      }
     }
   }
 }
@@ -927,7 +987,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
     const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
     const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials,
-    const unsigned short* __restrict__ tmask, const int* __restrict__ tlist, const int* __restrict__ toff, int cap) {
+    const unsigned short* __restrict__ tmask, const int2* __restrict__ tlist, const int* __restrict__ toff, int cap) {
   // LDS: two f16 images of the tile (hi, lo), 64-B rows with the 16-B chunks XOR-swizzled by row so that the
   // A-operand ds_read_b128 (16 rows x two neighbouring chunks per lane group) is conflict-free; double buffered
   __shared__ __attribute__((aligned(16))) unsigned char ybuf[2][2][FT * 64];
@@ -1043,31 +1103,33 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
     *reinterpret_cast<uint2*>(&ybuf[buf][1][off]) = make_uint2(lo[0], lo[1]);
   };
 
-  const int64_t ntiles = (n + FT - 1) / FT;
-  // This workgroup's tiles: those of its row block that several components reach (fullcov_tilelists, the last list); the
-  // tiles only one component reaches go to fullcov_single_kernel.
-  const int* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
+  // This workgroup's tiles: those of its row block that more than three components reach (fullcov_tilelists, the last
+  // list); the others go to fullcov_single_kernel.
+  const int2* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
   const int* so = toff + ((int64_t)c * gridDim.x + blockIdx.x) * kListOffs;
   const int li1 = so[kLists];
   int li = so[kLists - 1];
-  // bit k of a tile's mask clear: component k is out of reach of every row of the tile (fullcov_bounds)
-  const unsigned short* tm = (PRUNE && tmask) ? tmask + (int64_t)c * ntiles : nullptr;
+  // bit k of a tile's mask clear: component k is out of reach of every row of the tile (fullcov_bounds); the mask
+  // comes with the list entry
+  const bool tm = PRUNE && tmask != nullptr;
   unsigned mask_cur = 0xFFFFu, mask_nxt = 0xFFFFu;
   int64_t tile = 0, tile_nxt = 0;
   if (li < li1) {
-    tile = seg[li];
+    const int2 e = seg[li];
+    tile = e.x;
     gload(tile);
     lstore(0);
-    if (tm) mask_cur = tm[tile];
+    if (tm) mask_cur = (unsigned)e.y;
   }
   __syncthreads();
   int buf = 0;
   for (; li < li1; ++li, tile = tile_nxt) {
     const bool more = li + 1 < li1;
     if (more) {
-      tile_nxt = seg[li + 1];
+      const int2 e = seg[li + 1];
+      tile_nxt = e.x;
       gload(tile_nxt);
-      if (tm) mask_nxt = tm[tile_nxt];
+      if (tm) mask_nxt = (unsigned)e.y;
     }
     const unsigned tile_mask = __builtin_amdgcn_readfirstlane(mask_cur);
     mask_cur = mask_nxt;
@@ -1390,35 +1452,91 @@ __global__ __launch_bounds__(256) void fullcov_planes(const float* __restrict__ 
   }
 }
 
-// The tiles only ONE component reaches.  There every responsibility is 1 and a row's log-density is that component's:
-// no log-sum-exp, nothing to exchange between waves, no LDS staging and no barrier.  Every wave works through its own
-// lists of tiles (fullcov_tilelists) by itself, one component after the other: it loads the rows of a tile straight
-// into the A-operand layout of the residual product (lane = row 16 rt + ln, dims 8 g .. 8 g + 7; the next tile's rows
-// are in flight meanwhile), splits them into f16 pieces in registers, and runs the same two products as
-// fullcov_f16_kernel: residuals (four f16 products), |u|^2 by DPP row sums, then S0 += 1, S1 += u, S2 += u u^T.  Rows
-// past the end or beyond the f16 range of u (absurd parameters) get weight 0 through a per-wave LDS line.
+// A''_k = t_k A_k diag(1 / column scale) as the B operand of the residual product, in three f16 pieces (exact), per
+// chain and component, in the lane layout fullcov_single_kernel loads it with: apc[((chain K + k) 3 + piece) 2 + nt][lane]
+// (lane (ln, g): row 16 nt + ln of A, columns 8 g .. 8 g + 7); at[chain K + k] = the power of two t_k.  Computed once
+// per call: that kernel needs the pieces of its own component once per wave and those of a tile's other components
+// once per tile.
+__global__ __launch_bounds__(64) void fullcov_apieces(const float* __restrict__ Ainv, const float* __restrict__ cscale,
+                                                      f16x8* __restrict__ apc, float* __restrict__ at) {
+  const int lane = threadIdx.x, ln = lane & 15, g = lane >> 4;
+  const float* Ak = Ainv + (int64_t)blockIdx.x * DP * DP;
+  float v[2][8], amax = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int d = 8 * g + j;
+      const float sc = cscale[d];
+      v[nt][j] = sc > 0.f ? Ak[(16 * nt + ln) * DP + d] / sc : 0.f;
+      amax = fmaxf(amax, fabsf(v[nt][j]));
+    }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  const float t = fc_pow2_scale(amax);
+  if (lane == 0) at[blockIdx.x] = t;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    f16x8 a1, a2, a3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = v[nt][j] * t;
+      const _Float16 hi = fabsf(x) < 1024.f ? (_Float16)rintf(x) : (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      a1[j] = hi;
+      a2[j] = lo;
+      a3[j] = (_Float16)((x - (float)hi) - (float)lo);
+    }
+    apc[(((int64_t)blockIdx.x * 3 + 0) * 2 + nt) * 64 + lane] = a1;
+    apc[(((int64_t)blockIdx.x * 3 + 1) * 2 + nt) * 64 + lane] = a2;
+    apc[(((int64_t)blockIdx.x * 3 + 2) * 2 + nt) * 64 + lane] = a3;
+  }
+}
+
+// The tiles ONE component reaches, and those two or three reach.  On the first kind every responsibility is 1 and a
+// row's log-density is that component's: no log-sum-exp, nothing to exchange between waves, no LDS staging and no
+// barrier.  Every wave works through its own lists of tiles (fullcov_tilelists) by itself, one component after the
+// other: it loads the f16 pieces of a tile's rows (fullcov_planes) straight into the A-operand layout of the residual
+// product (lane = row 16 rt + ln, dims 8 g .. 8 g + 7; the next tile's rows are in flight meanwhile) and runs the same
+// two products as fullcov_f16_kernel: residuals (four f16 products), |u|^2 by DPP row sums, then S0 += 1, S1 += u,
+// S2 += u u^T.  A tile of the second kind stands in the list of each of its components: the wave first runs the
+// residual product for the OTHER components of the tile (their operand pieces come from fullcov_apieces) to get the
+// rows' log-sum-exp, then its own, and adds its component's sums with the responsibilities as weights (S0 += rho,
+// S1 += rho u, S2 += rho u u^T); the wave of the tile's first component also adds the rows' log-densities.  That is
+// c residual products per component instead of one shared by all -- and no wave of eight waits for the two or three
+// that have a component on the tile, which is what makes such tiles four times as expensive in fullcov_f16_kernel.
+// Rows past the end or beyond the f16 range of u (absurd parameters) get weight 0 through a per-wave LDS line.
 // Wave w owns components (w % K8) and (w % K8) + FW, K8 = FW / R; with R > 1 (K <= 4) wave w is replica w / K8 and
 // writes the partial sums of block R * blockIdx.x + replica.
-template <bool GRAD>
+template <bool GRAD, bool FEW>
 __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD ? 2 : 4))) void fullcov_single_kernel(
-    const float* __restrict__ Y, int64_t n, int D, int K, const float* __restrict__ Ainv,
-    const float* __restrict__ bvec, const float* __restrict__ blo, const float* __restrict__ cst,
-    const float* __restrict__ center, const float* __restrict__ cscale, int C, float* __restrict__ partials,
-    const int* __restrict__ tlist, const int* __restrict__ toff, int cap, const unsigned char* __restrict__ phi,
-    const unsigned char* __restrict__ plo) {
+    int64_t n, int D, int K, const float* __restrict__ bvec, const float* __restrict__ blo,
+    const float* __restrict__ cst, const f16x8* __restrict__ apc, const float* __restrict__ at, int C,
+    float* __restrict__ partials, const int2* __restrict__ tlist, const int* __restrict__ toff, int cap,
+    const unsigned char* __restrict__ phi, const unsigned char* __restrict__ plo) {
   __shared__ float sqw[FW][FT];
   __shared__ double lpw[FW];
-  // column centres and scales: read from LDS where they are used (registers are short)
-  __shared__ __attribute__((aligned(16))) float cms[2][DP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave number in a scalar register: the list entries are then scalar loads, which the waits for the rows'
+  // vector loads do not see -- as a vector load the next entry drew a vmcnt(0) right behind the prefetch of the rows)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 15, g = lane >> 4;
   const int c = blockIdx.y;
   const int R = fullcov_replicas(K), K8 = FW / R, kbase = wave % K8, rep = wave / K8;
-  if (tid < DP) { cms[0][tid] = center[tid]; cms[1][tid] = cscale[tid]; }
-  __syncthreads();
 
   constexpr int Q = 1 + DP + DP * DP;
   float* out = partials + (((int64_t)blockIdx.x * R + rep) * C + c) * ((int64_t)K * Q + 1);
+  const int2* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
+  const int* so = toff + ((int64_t)c * gridDim.x + blockIdx.x) * kListOffs;
+  // this instantiation's part of list j: the tiles component j alone reaches (FEW = false: the kernel writes the
+  // partial sums) or the shared tiles (FEW = true: launched after the other, it adds to them -- and has nothing to do
+  // when no list of the (chain, row block) has a second part)
+  auto first_entry = [&](int j) { return FEW ? so[kFewOff + j] : so[j]; };
+  auto end_entry = [&](int j) { return FEW ? so[j + 1] : so[kFewOff + j]; };
+  if constexpr (FEW) {
+    bool any = false;
+    for (int q = 0; q < 2; ++q) any = any || first_entry(wave + FW * q) < end_entry(wave + FW * q);
+    if (!__syncthreads_or(any)) return;
+  }
   double logp_acc = 0.0;
   const float row_level = fullcov_row_level(cst + (int64_t)c * K, K, D);
   f16x8 rawh[4], rawl[4];
@@ -1430,48 +1548,32 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
       rawl[rt] = *reinterpret_cast<const f16x8*>(plo + off);
     }
   };
-  const int* seg = tlist + ((int64_t)c * gridDim.x + blockIdx.x) * cap;
-  const int* so = toff + ((int64_t)c * gridDim.x + blockIdx.x) * kListOffs;
+  // operand pieces and constants of component kk of this chain
+  struct Comp {
+    f16x8 a1[2], a2[2], a3[2];
+    float inv_t, zb[2], bl[2], cq;
+  };
+  auto load_comp = [&](int kk, Comp& o) {
+    const int64_t ck = (int64_t)c * K + kk;
+    const float t = at[ck];
+    o.inv_t = 1.f / t;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      o.a1[nt] = apc[((ck * 3 + 0) * 2 + nt) * 64 + lane];
+      o.a2[nt] = apc[((ck * 3 + 1) * 2 + nt) * 64 + lane];
+      o.a3[nt] = apc[((ck * 3 + 2) * 2 + nt) * 64 + lane];
+      o.zb[nt] = -t * bvec[ck * DP + 16 * nt + ln];
+      o.bl[nt] = blo[ck * DP + 16 * nt + ln];
+    }
+    o.cq = cst[ck];
+  };
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
   for (int q = 0; q < 2; ++q) {
     const int k = kbase + FW * q;
     if (k >= K) break;
-    // A''_k as B operand of the residual product, three f16 pieces, as in fullcov_f16_kernel
-    f16x8 a1[2], a2[2], a3[2];
-    float inv_t, zb[2], bl[2];
-    {
-      const float* Ak = Ainv + ((int64_t)c * K + k) * DP * DP;
-      float v[2][8], amax = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int d = 8 * g + j;
-          const float sc = cms[1][d];
-          v[nt][j] = sc > 0.f ? Ak[(16 * nt + ln) * DP + d] / sc : 0.f;
-          amax = fmaxf(amax, fabsf(v[nt][j]));
-        }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-      const float t = fc_pow2_scale(amax);
-      inv_t = 1.f / t;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = v[nt][j] * t;
-          const _Float16 hi = fabsf(x) < 1024.f ? (_Float16)rintf(x) : (_Float16)x;
-          const _Float16 lo = (_Float16)(x - (float)hi);
-          a1[nt][j] = hi;
-          a2[nt][j] = lo;
-          a3[nt][j] = (_Float16)((x - (float)hi) - (float)lo);
-        }
-        zb[nt] = -t * bvec[((int64_t)c * K + k) * DP + 16 * nt + ln];
-        bl[nt] = blo[((int64_t)c * K + k) * DP + 16 * nt + ln];
-      }
-    }
-    const float cq = cst[c * K + k];
+    Comp own;
+    load_comp(k, own);
     f32x4 S2[2][2];
     float S1[2] = {0.f, 0.f}, S0 = 0.f;
 #pragma unroll
@@ -1479,71 +1581,105 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
 #pragma unroll
       for (int b = 0; b < 2; ++b) S2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int li = so[wave + FW * q];
-    const int li1 = so[wave + FW * q + 1];
-    int64_t tile = 0;
-    int tile_after = 0;                      // list entry li + 2: read a whole tile before its rows are asked for
+    int li = first_entry(wave + FW * q);
+    const int li1 = end_entry(wave + FW * q);
+    if (FEW && li >= li1) continue;          // nothing to add for this component
+    int2 ent = make_int2(0, 0), ent_after = make_int2(0, 0);   // ent_after: list entry li + 2, read a whole tile ahead
     if (li < li1) {
-      tile = seg[li];
-      gload(tile);
+      ent = seg[li];
+      gload(ent.x);
     }
-    if (li + 1 < li1) tile_after = seg[li + 1];
+    if (li + 1 < li1) ent_after = seg[li + 1];
     for (; li < li1; ++li) {
       // the tile's rows (A operands); the staging registers are then free for the next tile's rows
       f16x8 fh[4], fl[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) { fh[rt] = rawh[rt]; fl[rt] = rawl[rt]; }
-      const int64_t tile_cur = tile;
+      const int64_t tile_cur = ent.x;
+      const unsigned tile_mask = (unsigned)__builtin_amdgcn_readfirstlane(ent.y);
       if (li + 1 < li1) {
-        tile = tile_after;
-        gload(tile);
+        ent = ent_after;
+        gload(ent.x);
       }
-      if (li + 2 < li1) tile_after = seg[li + 2];
+      if (li + 2 < li1) ent_after = seg[li + 2];
       f32x4 u[GRAD ? 4 : 1][2];
-      f32x4 zc[2], zn[2];
-      float arow[4];                         // log-density of row 16 rt + 4 g + (ln >> 2)
-      // MFMA m (0..7) of a row tile: chain nt = m & 1, product m >> 1 of (yh a1, yl a1, yh a2, yh a3), on top of -t b_hi
-      auto mfma_step = [&](int rt, int m, f32x4 (&z)[2]) {
-        const int nt = m & 1, pr = m >> 1;
-        const f16x8 av = pr <= 1 ? a1[nt] : (pr == 2 ? a2[nt] : a3[nt]);
-        const f16x8 yv = pr == 1 ? fl[rt] : fh[rt];
-        const f32x4 c0 = {zb[nt], zb[nt], zb[nt], zb[nt]};
-        z[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yv, av, pr == 0 ? c0 : z[nt], 0, 0, 0);
-      };
-      float nrm[4];
-      Row16Sum4 rs;
+      // residual product of the tile with one component: arow[rt] = log-density of row 16 rt + 4 g + (ln >> 2) under
+      // it (without the weight's share of the log-sum-exp: cq holds the weight); KEEP: the residuals stay in u
+      auto resid = [&](auto keep, const Comp& o, float (&arow)[4]) {
+        constexpr bool KEEP = decltype(keep)::value;
+        f32x4 zc[2], zn[2];
+        // MFMA m (0..7) of a row tile: chain nt = m & 1, product m >> 1 of (yh a1, yl a1, yh a2, yh a3), on top of -t b_hi
+        auto mfma_step = [&](int rt, int m, f32x4 (&z)[2]) {
+          const int nt = m & 1, pr = m >> 1;
+          const f16x8 av = pr <= 1 ? o.a1[nt] : (pr == 2 ? o.a2[nt] : o.a3[nt]);
+          const f16x8 yv = pr == 1 ? fl[rt] : fh[rt];
+          const f32x4 c0 = {o.zb[nt], o.zb[nt], o.zb[nt], o.zb[nt]};
+          z[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yv, av, pr == 0 ? c0 : z[nt], 0, 0, 0);
+        };
+        float nrm[4];
+        Row16Sum4 rs;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) mfma_step(0, m, zc);
+        for (int m = 0; m < 8; ++m) mfma_step(0, m, zc);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          if (rt + 1 < 4) mfma_step(rt + 1, m, zn);
-          if (m < 4) {
-            const float u0 = fmaf(zc[0][m], inv_t, -bl[0]);
-            const float u1 = fmaf(zc[1][m], inv_t, -bl[1]);
-            if constexpr (GRAD) {
-              u[GRAD ? rt : 0][0][m] = u0;
-              u[GRAD ? rt : 0][1][m] = u1;
+          for (int m = 0; m < 8; ++m) {
+            if (rt + 1 < 4) mfma_step(rt + 1, m, zn);
+            if (m < 4) {
+              const float u0 = fmaf(zc[0][m], o.inv_t, -o.bl[0]);
+              const float u1 = fmaf(zc[1][m], o.inv_t, -o.bl[1]);
+              if constexpr (KEEP) {
+                u[KEEP ? rt : 0][0][m] = u0;
+                u[KEEP ? rt : 0][1][m] = u1;
+              }
+              nrm[m] = fmaf(u1, u1, u0 * u0);
+            } else {
+              rs.template step<true>(m - 4, nrm);
             }
-            nrm[m] = fmaf(u1, u1, u0 * u0);
-          } else {
-            rs.template step<true>(m - 4, nrm);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          arow[rt] = o.cq - 0.5f * rs.d0;
+          if (rt + 1 < 4) { zc[0] = zn[0]; zc[1] = zn[1]; }
         }
-        arow[rt] = cq - 0.5f * rs.d0;
-        if (rt + 1 < 4) { zc[0] = zn[0]; zc[1] = zn[1]; }
+      };
+      // the tile's other components: running log-sum-exp of their log-densities per row
+      const unsigned others = tile_mask & ~(1u << k);
+      float om[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, os[4] = {0.f, 0.f, 0.f, 0.f};
+      for (unsigned rest = FEW ? others : 0u; rest != 0; rest &= rest - 1) {      // (the same in every lane)
+        Comp oth;
+        load_comp(__builtin_ctz(rest), oth);
+        float ao[4];
+        resid(std::false_type{}, oth, ao);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const float mn = fmaxf(om[rt], ao[rt]);
+          const float mm = mn > -INFINITY ? mn : 0.f;
+          os[rt] = os[rt] * __expf(om[rt] - mm) + __expf(ao[rt] - mm);      // (a NaN log-density stays in the sum)
+          om[rt] = mn;
+        }
       }
-      // log-densities (one of the four lanes that hold a row's value adds it) and the rows' weights
+      float arow[4];
+      resid(std::integral_constant<bool, GRAD>{}, own, arow);
+      // log-densities (one of the four lanes that hold a row's value adds it; on a shared tile only the wave of its
+      // first component) and the rows' weights (the square roots of the responsibilities)
+      const bool adds_logp = (tile_mask & ((1u << k) - 1u)) == 0;
       bool ok = true;
       float sv[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const bool valid = tile_cur * FT + 16 * rt + 4 * g + (ln >> 2) < n;
         const float a = arow[rt];
-        if (valid && (ln & 3) == 0) logp_acc += (double)(a - row_level);
-        sv[rt] = valid ? (a > cq - 1.5e9f ? 1.f : (a != a ? a : 0.f)) : 0.f;
+        float lp = a, wgt = 1.f;
+        if constexpr (FEW) {
+          const float mn = fmaxf(om[rt], a);
+          const float mm = mn > -INFINITY ? mn : 0.f;
+          const float st = os[rt] * __expf(om[rt] - mm) + __expf(a - mm);
+          lp = mm + __logf(st);
+          wgt = a > -INFINITY ? sqrtf(__expf(a - lp)) : 0.f;
+          if (a != a) wgt = a;
+        }
+        if (valid && adds_logp && (ln & 3) == 0) logp_acc += (double)(lp - row_level);
+        sv[rt] = valid ? (a > own.cq - 1.5e9f ? wgt : (a != a ? a : 0.f)) : 0.f;
         ok = ok && sv[rt] == 1.f;
         if (GRAD && (ln & 3) == 0) S0 = fmaf(sv[rt], sv[rt], S0);
       }
@@ -1570,15 +1706,15 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
               }
             } else {
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-              const float sr0 = sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3)];
-              const float sr1 = sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3) + 1];
-              const float w0 = sr0 * u[2 * m + (j >> 2)][nt][j & 3];
-              const float w1 = sr1 * u[2 * m + (j >> 2)][nt][(j & 3) + 1];
-              S1[nt] = fmaf(sr0, w0, S1[nt]);
-              S1[nt] = fmaf(sr1, w1, S1[nt]);
-              fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
-            }
+              for (int j = 0; j < 8; j += 2) {
+                const float sr0 = sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3)];
+                const float sr1 = sqw[wave][32 * m + 16 * (j >> 2) + 4 * g + (j & 3) + 1];
+                const float w0 = sr0 * u[2 * m + (j >> 2)][nt][j & 3];
+                const float w1 = sr1 * u[2 * m + (j >> 2)][nt][(j & 3) + 1];
+                S1[nt] = fmaf(sr0, w0, S1[nt]);
+                S1[nt] = fmaf(sr1, w1, S1[nt]);
+                fc_split_pair(w0, w1, hw[j >> 1], lw[j >> 1]);
+              }
             }
             wh[nt] = __builtin_bit_cast(f16x8, (u32x4){hw[0], hw[1], hw[2], hw[3]});
             wl[nt] = __builtin_bit_cast(f16x8, (u32x4){lw[0], lw[1], lw[2], lw[3]});
@@ -1593,26 +1729,27 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
             }
         }
       }
-    }
+}
 
     // ---- partials of (row block, replica, chain), component k: the layout of fullcov_f16_kernel ----
     if constexpr (GRAD) {
       float s0 = S0;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) s0 += __shfl_xor(s0, off, 64);
-      if (lane == 0) out[(int64_t)k * Q] = s0;
+      auto put = [&](int64_t idx, float v) { out[idx] = FEW ? out[idx] + v : v; };
+      if (lane == 0) put((int64_t)k * Q, s0);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         float s1 = S1[nt];
         s1 += __shfl_xor(s1, 16, 64);
         s1 += __shfl_xor(s1, 32, 64);
-        if (g == 0) out[(int64_t)k * Q + 1 + 16 * nt + ln] = s1;
+        if (g == 0) put((int64_t)k * Q + 1 + 16 * nt + ln, s1);
 #pragma unroll
         for (int b = nt; b < 2; ++b)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            out[(int64_t)k * Q + 1 + DP + (16 * nt + 4 * g + i) * DP + 16 * b + ln] = S2[nt][b][i];
-            if (b != nt) out[(int64_t)k * Q + 1 + DP + (16 * b + ln) * DP + 16 * nt + 4 * g + i] = S2[nt][b][i];
+            put((int64_t)k * Q + 1 + DP + (16 * nt + 4 * g + i) * DP + 16 * b + ln, S2[nt][b][i]);
+            if (b != nt) put((int64_t)k * Q + 1 + DP + (16 * b + ln) * DP + 16 * nt + 4 * g + i, S2[nt][b][i]);
           }
       }
     }
@@ -1624,7 +1761,7 @@ __global__ __launch_bounds__(64 * FW) __attribute__((amdgpu_waves_per_eu(2, GRAD
   if (lane == 0 && kbase == 0) {
     double t = 0.0;
     for (int w = 0; w < K8; ++w) t += lpw[rep * K8 + w];
-    out[(int64_t)K * Q] = (float)t;
+    out[(int64_t)K * Q] = FEW ? (float)((double)out[(int64_t)K * Q] + t) : (float)t;
   }
 }
 
@@ -1760,9 +1897,9 @@ constexpr int kStatBlocks = 2048;
 constexpr size_t kStatFloats = 2 * (size_t)kStatBlocks * DP + 2 * (size_t)kStatBlocks * DP + 2 * DP;
 
 // tiles per row block, at most
-int fullcov_list_cap(int64_t n, int nb) {
+int fullcov_list_cap(int64_t n, int nb) {      // entries: a tile two or three components reach stands in a list of each
   const int64_t ntiles = (n + FT - 1) / FT;
-  return (int)((ntiles + nb - 1) / nb) + 1;
+  return kFewMax * ((int)((ntiles + nb - 1) / nb) + 1);
 }
 
 // floats for the far-component test and the tile lists: per-tile centre + radius, |A_k|_2 bounds, the tiles'
@@ -1770,18 +1907,20 @@ int fullcov_list_cap(int64_t n, int nb) {
 size_t fullcov_tile_floats(int64_t n, int c, int k) {
   const size_t ntiles = (size_t)((n + FT - 1) / FT);
   const size_t nb = (size_t)fullcov_blocks(n, c), nbg = (size_t)fullcov_blocks(n, c, true);
-  const size_t lists = (size_t)c * nb * ((size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
-  const size_t listsg = (size_t)c * nbg * ((size_t)fullcov_list_cap(n, (int)nbg) + kListOffs);
+  // (an entry is two ints)
+  const size_t lists = (size_t)c * nb * (2 * (size_t)fullcov_list_cap(n, (int)nb) + kListOffs);
+  const size_t listsg = (size_t)c * nbg * (2 * (size_t)fullcov_list_cap(n, (int)nbg) + kListOffs);
   const size_t ngroups = (ntiles + 63) / 64;
   // + the flag "some tile is on a single-component list" and the two f16 planes of the rows (16-B aligned)
   return (ntiles + ngroups) * (DP + 1) + 3 * (size_t)c * k + 2 * (size_t)c * ngroups * k + 2 +
-         ((size_t)c * ntiles + 1) / 2 + 2 +
+         ((size_t)c * ntiles + 1) / 2 + 4 +
          (lists > listsg ? lists : listsg) + 8 + ntiles * FT * DP;
 }
 
 size_t bvi_ws_gmm_fullcov(int64_t n, int c, int d, int k) {
   (void)d;
-  const size_t prep = (size_t)c * k * (DP * DP + 2 * DP + 1);
+  // A, b (two floats), constants; t and the f16 pieces of A'' (6 KB per chain and component, 16-B aligned)
+  const size_t prep = (size_t)c * k * (DP * DP + 2 * DP + 1) + (size_t)c * k * (1 + 3 * 2 * 64 * 4) + 4;
   // partial sums: one set per row block from the kernel of the tiles several components reach, R sets per row
   // block from the kernel of the tiles one component reaches
   const size_t part = (size_t)fullcov_blocks(n, c) * (1 + fullcov_replicas(k)) * c * ((size_t)k * (1 + DP + DP * DP) + 1);
@@ -1864,7 +2003,11 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   float* bvec = Ainv + (size_t)c * k * DP * DP;
   float* blo = bvec + (size_t)c * k * DP;
   float* cst = blo + (size_t)c * k * DP;
-  float* partials = cst + (size_t)c * k;
+  float* at = cst + (size_t)c * k;
+  float* apc0 = at + (size_t)c * k;
+  apc0 += (4 - (((uintptr_t)apc0 >> 2) & 3)) & 3;                         // 16-B aligned
+  f16x8* apc = reinterpret_cast<f16x8*>(apc0);
+  float* partials = apc0 + (size_t)c * k * (3 * 2 * 64 * 4);
   const int64_t ntiles = (n + FT - 1) / FT;
   const int nblk = fullcov_blocks(n, c, grad != nullptr), reps = fullcov_replicas(k), cap = fullcov_list_cap(n, nblk);
   const size_t pstride = (size_t)c * ((size_t)k * (1 + DP + DP * DP) + 1);
@@ -1878,8 +2021,10 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
   gb0 += ((uintptr_t)gb0 & 7) ? 1 : 0;                 // float2 entries
   float2* gbounds = reinterpret_cast<float2*>(gb0);
   unsigned short* tmask = reinterpret_cast<unsigned short*>(gb0 + 2 * (size_t)c * ngroups * k);
-  int* tlist = reinterpret_cast<int*>(gb0 + 2 * (size_t)c * ngroups * k + ((size_t)c * ntiles + 1) / 2 + 2);
-  int* toff = tlist + (size_t)c * nblk * cap;
+  float* tl0 = gb0 + 2 * (size_t)c * ngroups * k + ((size_t)c * ntiles + 1) / 2 + 2;
+  tl0 += ((uintptr_t)tl0 & 7) ? 1 : 0;                                    // (tile, mask) entries: 8-B aligned
+  int2* tlist = reinterpret_cast<int2*>(tl0);
+  int* toff = reinterpret_cast<int*>(tlist + (size_t)c * nblk * cap);
   int* any_single = toff + (size_t)c * nblk * kListOffs;
   any_single += (4 - (((uintptr_t)any_single >> 2) & 3)) & 3;            // 16-B aligned; the planes follow at + 16 B
   unsigned char* phi = reinterpret_cast<unsigned char*>(any_single + 4);
@@ -1955,7 +2100,8 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
       if (me != hipSuccess) return (int)me;
     }
     hipLaunchKernelGGL(fullcov_tilelists, dim3(nblk, c), dim3(64), 0, s, lists_from_masks ? tmask_arg : (const unsigned short*)nullptr,
-                       ntiles, lists_from_masks ? k : 16, cap, tlist, toff, any_single);
+                       ntiles, lists_from_masks ? k : 16, cap, tlist, toff, any_single, grad != nullptr ? 1 : 0);
+    hipLaunchKernelGGL(fullcov_apieces, dim3(c * k), dim3(64), 0, s, (const float*)Ainv, (const float*)cscale, apc, at);
     if (ntiles > 0 && !packed) {
       const int pblocks = (int)(ntiles > 4096 ? 4096 : ntiles);
       hipLaunchKernelGGL(fullcov_planes, dim3(pblocks), dim3(256), 0, s, Y, n, d, ntiles, (const float*)center,
@@ -1965,20 +2111,24 @@ int bvi_launch_gmm_fullcov(const float* Y, int64_t n, int d, int k, const float*
 #define BVI_FC16D(KQ, GRAD, PRUNE)                                                                                  \
   hipLaunchKernelGGL((fullcov_f16_kernel<KQ, GRAD, PRUNE>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,    \
                      (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
-                     c, partials, tmask_arg, (const int*)tlist, (const int*)toff, cap)
+                     c, partials, tmask_arg, (const int2*)tlist, (const int*)toff, cap)
+#define BVI_FC1(GRAD, FEW)                                                                                           \
+  hipLaunchKernelGGL((fullcov_single_kernel<GRAD, FEW>), grid, dim3(64 * FW), 0, s, n, d, k, (const float*)bvec,          \
+                     (const float*)blo, (const float*)cst, (const f16x8*)apc, (const float*)at, c,                          \
+                     partials + (size_t)nblk * pstride, (const int2*)tlist, (const int*)toff, cap,                         \
+                     (const unsigned char*)phi, (const unsigned char*)plo)
 #define BVI_FC16(KQ, GRAD)                                                                                          \
   BVI_FC16D(KQ, GRAD, false);                                                                                        \
   if (prune) BVI_FC16D(KQ, GRAD, true);                                                                              \
-  hipLaunchKernelGGL((fullcov_single_kernel<GRAD>), grid, dim3(64 * FW), 0, s, Y, n, d, k, (const float*)Ainv,            \
-                     (const float*)bvec, (const float*)blo, (const float*)cst, (const float*)center, (const float*)cscale, \
-                     c, partials + (size_t)nblk * pstride, (const int*)tlist, (const int*)toff, cap,                      \
-                     (const unsigned char*)phi, (const unsigned char*)plo)
+  BVI_FC1(GRAD, false);                                                                                                \
+  if (prune) BVI_FC1(GRAD, true)
     if (k <= FW) {
       if (grad) { BVI_FC16(1, true); } else { BVI_FC16(1, false); }
     } else {
       if (grad) { BVI_FC16(2, true); } else { BVI_FC16(2, false); }
     }
 #undef BVI_FC16
+#undef BVI_FC1
 #undef BVI_FC16D
     nb_total = nblk * (1 + reps);
   }

@@ -7,9 +7,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'bayesian-inference_amd'))
 from bayes_vi_amd import _native as nat
+if '--lib' in sys.argv:
+    nat._LIB_PATH = os.path.abspath(sys.argv[sys.argv.index('--lib') + 1])
 n, d, k, c = 1_000_000, 32, 16, 64
 dev = torch.device('cuda:0'); ws = nat.Workspace(dev)
-for spread in (8.0, 4.0, 2.0, 1.2, 0.8, 0.4):
+spreads = [float(x) for x in sys.argv[sys.argv.index('--spreads') + 1].split(',')] if '--spreads' in sys.argv else [8.0, 4.0, 2.0, 1.2, 0.8, 0.4]
+for spread in spreads:
     g = torch.Generator(device=dev); g.manual_seed(int(10 * spread))
     centers = spread * torch.randn(k, d, generator=g, device=dev)
     Y = (centers[torch.randint(0, k, (n,), generator=g, device=dev)] + torch.randn(n, d, generator=g, device=dev)).contiguous()
