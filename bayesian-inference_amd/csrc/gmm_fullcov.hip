@@ -144,47 +144,59 @@ __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ t
   float md2 = (rg == 0 && j < D) ? (mu[j] - center[j]) * (mu[j] - center[j]) : 0.f, unused = 0.f;
   block_reduce2(md2, unused, false);                                // (its barriers also publish Af)
   if (tid == 0) mudist[c * K + k] = sqrtf(md2);
-  float cmax[2] = {0.f, 0.f};
-  for (int i = rg; i < DP; i += 8) {
+  // Every product below: thread (rg, j) takes entries (rg + 8 r, j), r < 4, of both matrices -- one read of column j
+  // per step m for the four rows, the rows' own entries as broadcast reads -- keeps them in registers over the
+  // reduction that finds the largest entry, and stores them divided by it (the next product then needs no scaling).
+  float v[2][4], cmax[2] = {0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float v = 0.f;
+  for (int q = 0; q < 2; ++q) {
 #pragma unroll
-      for (int m = 0; m < DP; ++m) v = fmaf(Af[q][m][i], Af[q][m][j], v);
-      Mq[q][0][i][j] = v;
-      cmax[q] = fmaxf(cmax[q], fabsf(v));
+    for (int r = 0; r < 4; ++r) v[q][r] = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < DP; ++m) {
+      const float bcol = Af[q][m][j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[q][r] = fmaf(Af[q][m][rg + 8 * r], bcol, v[q][r]);      // M = A^T A
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmax[q] = fmaxf(cmax[q], fabsf(v[q][r]));
   }
   float scale[2][kNormSquarings + 1];
-  block_reduce2(cmax[0], cmax[1], true);
-  scale[0][0] = cmax[0];
-  scale[1][0] = cmax[1];
   int cur = 0;
 #pragma unroll
-  for (int sq = 0; sq < kNormSquarings; ++sq) {
-    cmax[0] = cmax[1] = 0.f;
+  for (int sq = 0; sq <= kNormSquarings; ++sq) {
+    block_reduce2(cmax[0], cmax[1], true);
+    scale[0][sq] = cmax[0];
+    scale[1][sq] = cmax[1];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const float inv = scale[q][sq] > 0.f ? 1.f / scale[q][sq] : 0.f;
-      for (int i = rg; i < DP; i += 8) {
-        float v = 0.f;
 #pragma unroll
-        for (int m = 0; m < DP; ++m) v = fmaf(Mq[q][cur][i][m] * inv, Mq[q][cur][m][j] * inv, v);
-        Mq[q][cur ^ 1][i][j] = v;
-        cmax[q] = fmaxf(cmax[q], fabsf(v));
-      }
+      for (int r = 0; r < 4; ++r) Mq[q][cur][rg + 8 * r][j] = v[q][r] * inv;
     }
-    block_reduce2(cmax[0], cmax[1], true);
-    scale[0][sq + 1] = cmax[0];
-    scale[1][sq + 1] = cmax[1];
+    __syncthreads();
+    if (sq == kNormSquarings) break;
+    cmax[0] = cmax[1] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[q][r] = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < DP; ++m) {
+        const float bcol = Mq[q][cur][m][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[q][r] = fmaf(Mq[q][cur][rg + 8 * r][m], bcol, v[q][r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cmax[q] = fmaxf(cmax[q], fabsf(v[q][r]));
+    }
     cur ^= 1;
   }
   float fro[2] = {0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const float inv = scale[q][kNormSquarings] > 0.f ? 1.f / scale[q][kNormSquarings] : 0.f;
-    for (int i = rg; i < DP; i += 8) fro[q] = fmaf(Mq[q][cur][i][j] * inv, Mq[q][cur][i][j] * inv, fro[q]);
-  }
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fro[q] = fmaf(Mq[q][cur][rg + 8 * r][j], Mq[q][cur][rg + 8 * r][j], fro[q]);
   block_reduce2(fro[0], fro[1], false);
   if (tid == 0) {
     // lambda(M) <= s0 sqrt(s1 sqrt(s2 ... sqrt(s_p |N_p|_F)))
