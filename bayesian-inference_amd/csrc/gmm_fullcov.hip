@@ -106,10 +106,7 @@ __global__ void fullcov_prepare(const float* __restrict__ theta, int C, int K, i
 //   mudist = |mu_k - center|.
 // One workgroup of 256 threads per (chain, component): thread (rg, j) owns rows rg, rg + 8, ... of column j; the two
 // matrices go through the same steps side by side.
-#ifndef FC_NSQ
-#define FC_NSQ 6
-#endif
-constexpr int kNormSquarings = FC_NSQ;
+constexpr int kNormSquarings = 6;
 __global__ __launch_bounds__(256) void fullcov_anorm(const float* __restrict__ theta, int K, int D,
                                                      const float* __restrict__ center, const float* __restrict__ Ainv,
                                                      float* __restrict__ anorm, float* __restrict__ mudist,
